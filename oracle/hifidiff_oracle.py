@@ -1,0 +1,400 @@
+"""CPU oracle for the HifiDiff refiner sampling path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a CPU restatement (torch-CPU functional ops, fp32) of the
+reference algorithm, used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the
+*checker*.  Nothing in the product path (hifidiff_amd/) imports it; the product fails loudly when the
+HIP library is missing.
+
+Pinned: the network part is checked against golden vectors produced by importing the reference itself
+(oracle/make_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py).
+PARITY UNPINNED for the scheduler: diffusers==0.32.2 (requirements.txt:6 of the reference) is a
+third-party dependency that is not vendored and not installed here; `DDIMScheduler` / `DDPMScheduler`
+below restate its published arithmetic (Song et al. 2021 eq. 12, Ho et al. 2020 eq. 7/11) anchored on
+the reference call sites test_refiner.py:85-91,166-171 and train_refiner.py:337-348.
+
+Every function works on a flat `{state_dict key: tensor}` mapping `P` with the reference's key
+names (hifidiff_amd/arch.py), NCHW fp32 tensors, eval-mode BatchNorm.
+
+`Prec` selects the arithmetic:
+  Prec(False)  exact fp32, op order of the reference   -> compared with the golden vectors
+  Prec(True)   same maths with the MFMA operands (weights and the activation tile fed to each
+               1x1 / 2x2 / 3x3 GEMM) rounded to bf16 at exactly the points the HIP kernels round
+               them (DESIGN.md "Numerics"), BatchNorm folded into the conv before rounding.
+               HIP-vs-oracle differences are then accumulation order only.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------- precision
+class Prec:
+    def __init__(self, emulate_bf16=False):
+        self.emulate = bool(emulate_bf16)
+
+    def q(self, x):
+        """Round an MFMA operand (activation tile or weight) to bf16 (RNE) in emulation mode."""
+        return x.to(torch.bfloat16).to(torch.float32) if self.emulate else x
+
+
+FP32 = Prec(False)
+BF16 = Prec(True)
+
+
+def _gemm_conv(x, w, b, prec, stride=1, padding=0):
+    """A dense conv executed as an MFMA GEMM: operands rounded, fp32 accumulate, fp32 bias."""
+    return F.conv2d(prec.q(x), prec.q(w), b, stride=stride, padding=padding)
+
+
+def _gemm_linear(x, w, b, prec):
+    return F.linear(prec.q(x), prec.q(w), b)
+
+
+def _bn_affine(P, p, eps=1e-5):
+    """Eval-mode BatchNorm2d as y = x*s + o (torch.nn.BatchNorm2d defaults, eps 1e-5)."""
+    s = P[p + ".weight"] / torch.sqrt(P[p + ".running_var"] + eps)
+    o = P[p + ".bias"] - P[p + ".running_mean"] * s
+    return s, o
+
+
+def _conv_bn(x, P, conv, bn, prec, stride=1, padding=0):
+    """conv -> BatchNorm(eval).  fp32: in that order (as the reference does); bf16 emulation: BN is
+    folded into the weight and bias first, then the folded weight is rounded (what the packer stores)."""
+    w = P[conv + ".weight"]
+    b = P.get(conv + ".bias")
+    if not prec.emulate:
+        y = F.conv2d(x, w, b, stride=stride, padding=padding)
+        return F.batch_norm(y, P[bn + ".running_mean"], P[bn + ".running_var"],
+                            P[bn + ".weight"], P[bn + ".bias"], False, 0.0, 1e-5)
+    s, o = _bn_affine(P, bn)
+    wf = w * s.view(-1, 1, 1, 1)
+    bf = o if b is None else b * s + o
+    return F.conv2d(prec.q(x), prec.q(wf), bf, stride=stride, padding=padding)
+
+
+# --------------------------------------------------------------------------------------- primitives
+def layernorm2d(x, w, b, eps=1e-6):
+    """Per-pixel LayerNorm over channels, biased variance (reference utils.py:16-24, eps utils.py:47)."""
+    mu = x.mean(1, keepdim=True)
+    var = (x - mu).pow(2).mean(1, keepdim=True)
+    y = (x - mu) / (var + eps).sqrt()
+    return w.view(1, -1, 1, 1) * y + b.view(1, -1, 1, 1)
+
+
+def simple_gate(x):
+    """Channel j times channel j+C (reference utils.py:57-60); works on (B,2C,H,W) and (B,2C)."""
+    a, b = x.chunk(2, dim=1)
+    return a * b
+
+
+def sinusoidal_embedding(t, dim=128):
+    """[sin(t f_k), cos(t f_k)], f_k = exp(-k ln(1e4)/(dim/2-1)) (models/denoiser/model.py:22-29)."""
+    half = dim // 2
+    f = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    e = t.to(torch.float32)[:, None] * f[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def time_embedding(P, t, prefix="denoiser"):
+    """time_mlp: SinusoidalPosEmb -> Linear(128,1024) -> SimpleGate -> Linear(512,512)
+    (models/denoiser/model.py:152-157).  Kept fp32 in both precisions (HIP FiLM path is fp32)."""
+    e = sinusoidal_embedding(t, 128)
+    h = F.linear(e, P[prefix + ".time_mlp.1.weight"], P[prefix + ".time_mlp.1.bias"])
+    return F.linear(simple_gate(h), P[prefix + ".time_mlp.3.weight"], P[prefix + ".time_mlp.3.bias"])
+
+
+def film_vectors(P, p, temb):
+    """Block FiLM: SimpleGate -> Linear(256,4C), chunked shift_att, scale_att, shift_ffn, scale_ffn
+    (conditional_naf.py:18-22,103-110).  Returns four (B,C,1,1) tensors."""
+    v = F.linear(simple_gate(temb), P[p + ".mlp.1.weight"], P[p + ".mlp.1.bias"])
+    return [c[:, :, None, None] for c in v.chunk(4, dim=1)]
+
+
+# --------------------------------------------------------------------------------------- NAF blocks
+def _naf_body(P, p, inp, film, prec):
+    """Shared body of ConditionalNAFBlock.forward (conditional_naf.py:108-136) and NAFBlock.forward
+    (models/fpg/naf.py:105-126); `film` is None for the plain block."""
+    x = layernorm2d(inp, P[p + ".norm1.weight"], P[p + ".norm1.bias"])
+    if film is not None:
+        x = x * (film[1] + 1) + film[0]
+    x = _gemm_conv(x, P[p + ".conv1.weight"], P[p + ".conv1.bias"], prec)
+    c2 = x.shape[1]
+    x = F.conv2d(x, P[p + ".conv2.weight"], P[p + ".conv2.bias"], padding=1, groups=c2)  # fp32 VALU
+    g = simple_gate(x)
+    pooled = g.mean(dim=(2, 3), keepdim=True)                       # pooled from the unrounded gate
+    s = _gemm_conv(pooled, P[p + ".sca.1.weight"], P[p + ".sca.1.bias"], prec)
+    x = prec.q(g) * s                                               # G is stored bf16 by the HIP path
+    x = _gemm_conv(x, P[p + ".conv3.weight"], P[p + ".conv3.bias"], prec)
+    y = inp + x * P[p + ".beta"]
+    x = layernorm2d(y, P[p + ".norm2.weight"], P[p + ".norm2.bias"])
+    if film is not None:
+        x = x * (film[3] + 1) + film[2]
+    x = _gemm_conv(x, P[p + ".conv4.weight"], P[p + ".conv4.bias"], prec)
+    x = simple_gate(x)
+    x = _gemm_conv(x, P[p + ".conv5.weight"], P[p + ".conv5.bias"], prec)
+    return y + x * P[p + ".gamma"]
+
+
+def cond_naf_block(P, p, x, temb, prec=FP32):
+    return _naf_body(P, p, x, film_vectors(P, p, temb), prec)
+
+
+def naf_block(P, p, x, prec=FP32):
+    return _naf_body(P, p, x, None, prec)
+
+
+# --------------------------------------------------------------------------------------- HCA
+def hca_gates(P, p, f_g, prec=FP32):
+    """Channel gate w_c (B,C,1,1) and spatial gate w_s (B,1,H,W) of HybridCrossAttention
+    (models/fpg/hca.py:33-48).  They depend on the prior only, so the HIP path computes them once."""
+    B = f_g.shape[0]
+    pooled = (F.adaptive_avg_pool2d(f_g, 1) + F.adaptive_max_pool2d(f_g, 1)).reshape(B, -1)
+    h = torch.relu(_gemm_linear(pooled, P[p + ".channel_mlp.0.weight"], P[p + ".channel_mlp.0.bias"], prec))
+    w_c = torch.sigmoid(_gemm_linear(h, P[p + ".channel_mlp.2.weight"], P[p + ".channel_mlp.2.bias"], prec))
+    h = torch.relu(_conv_bn(f_g, P, p + ".spatial_mlp.0", p + ".spatial_mlp.1", prec))
+    w_s = torch.sigmoid(_conv_bn(h, P, p + ".spatial_mlp.3", p + ".spatial_mlp.4", prec))
+    return w_c.reshape(B, -1, 1, 1), w_s
+
+
+def hca_apply(P, p, w_c, w_s, f_d, prec=FP32):
+    """f_o = ReLU(BN(conv3x3(f_d + w_c f_d + w_s f_d))) (models/fpg/hca.py:28-29,21-23)."""
+    if prec.emulate:
+        f_o = f_d * (1.0 + w_c + w_s)          # one fused gate multiply in the A-loader
+    else:
+        f_o = f_d + w_c * f_d + w_s * f_d
+    return torch.relu(_conv_bn(f_o, P, p + ".fused_mlp.0", p + ".fused_mlp.1", prec, padding=1))
+
+
+def hca(P, p, f_g, f_d, prec=FP32):
+    w_c, w_s = hca_gates(P, p, f_g, prec)
+    return hca_apply(P, p, w_c, w_s, f_d, prec)
+
+
+# --------------------------------------------------------------------------------------- FPG
+def _up_shuffle(x, w, r, prec):
+    y = _gemm_conv(x, w, None, prec)
+    return F.pixel_shuffle(y, r) if r > 1 else y
+
+
+def fpg(P, x, prefix="fpg", prec=FP32):
+    """FacialPriorGuidance.forward (models/fpg/model.py:46-64): five prior maps, coarsest first."""
+    p = prefix
+    x = F.conv2d(x, P[p + ".intro.weight"], P[p + ".intro.bias"], padding=1)      # fp32 direct conv
+    skips = []
+    for i, n in enumerate((2, 2, 4, 8)):
+        for j in range(n):
+            x = naf_block(P, f"{p}.encoders.{i}.{j}", x, prec)
+        skips.append(x)
+        x = _gemm_conv(x, P[f"{p}.downs.{i}.weight"], P[f"{p}.downs.{i}.bias"], prec, stride=2)
+    x = _up_shuffle(x, P[p + ".convs.0.0.weight"], 1, prec)
+    priors = [x]
+    for i, skip in zip(range(1, 5), skips[::-1]):
+        x = _up_shuffle(x, P[f"{p}.convs.{i}.0.weight"], 2, prec) + skip
+        priors.append(x)
+    return priors
+
+
+# --------------------------------------------------------------------------------------- IDC
+def _store(x, prec):
+    """ResNet activations live in bf16 between the HIP conv kernels."""
+    return prec.q(x)
+
+
+def resnet50(P, x, prefix="idc", prec=FP32):
+    """ResNet.forward / Bottleneck.forward (models/idc/model.py:39-55,122-135): (B,3,128,128) ->
+    (B,2048,1,1).  Every conv has a bias and a BatchNorm (eval)."""
+    p = prefix
+    x = _store(torch.relu(_conv_bn(x, P, p + ".conv1", p + ".batch_norm1", prec, stride=2, padding=3)), prec)
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, nblk in enumerate((3, 4, 6, 3), start=1):
+        for b in range(nblk):
+            q = f"{p}.layer{li}.{b}"
+            stride = 2 if (b == 0 and li > 1) else 1
+            idn = x
+            y = _store(torch.relu(_conv_bn(x, P, q + ".conv1", q + ".batch_norm1", prec)), prec)
+            y = _store(torch.relu(_conv_bn(y, P, q + ".conv2", q + ".batch_norm2", prec, stride=stride, padding=1)), prec)
+            y = _conv_bn(y, P, q + ".conv3", q + ".batch_norm3", prec)
+            if b == 0:
+                idn = _store(_conv_bn(x, P, q + ".i_downsample.0", q + ".i_downsample.1", prec, stride=stride), prec)
+            x = _store(torch.relu(y + idn), prec)
+    return x.mean(dim=(2, 3), keepdim=True)
+
+
+# --------------------------------------------------------------------------------------- denoiser
+def normalize_timesteps(timesteps, batch):
+    """Scalar / 0-d / (1,) / (B,) int or float -> fp32 (B,) (models/denoiser/model.py:218-229)."""
+    if isinstance(timesteps, (int, float)):
+        return torch.full((batch,), float(timesteps), dtype=torch.float32)
+    t = torch.as_tensor(timesteps)
+    if t.dim() == 0:
+        return torch.full((batch,), float(t), dtype=torch.float32)
+    t = t.to(torch.float32)
+    if t.shape[0] == 1 and batch > 1:
+        t = t.expand(batch)
+    return t
+
+
+class Conditioning:
+    """Step-invariant conditioning of one batch: priors, HCA gates, idc term (hoisted out of the loop;
+    the reference recomputes them every step, models/refiner.py:33-34)."""
+
+    def __init__(self, P, cr_latent, cr_face=None, id_emb=None, prec=FP32, prefix="denoiser"):
+        self.priors = fpg(P, cr_latent, "fpg", prec)
+        if id_emb is None:
+            id_emb = resnet50(P, cr_face, "idc", prec)
+        self.id_emb = id_emb
+        self.gates = [hca_gates(P, f"{prefix}.hcas.{i}", self.priors[i], prec) for i in range(5)]
+        self.idc = _gemm_conv(id_emb, P[prefix + ".idc_conv.weight"], P[prefix + ".idc_conv.bias"], prec)
+
+
+def fused_denoiser(P, latents, timesteps, priors=None, id_emb=None, prec=FP32, prefix="denoiser", cond=None):
+    """FusedDenoiser.forward (models/denoiser/model.py:217-266) -> eps (B,4,L,L).
+
+    Either pass `priors` + `id_emb` (the reference signature) or a prepared `Conditioning`."""
+    p = prefix
+    B = latents.shape[0]
+    t = normalize_timesteps(timesteps, B)
+    temb = time_embedding(P, t, p)
+    if cond is None:
+        gates = [hca_gates(P, f"{p}.hcas.{i}", priors[i], prec) for i in range(5)]
+        idc = _gemm_conv(id_emb, P[p + ".idc_conv.weight"], P[p + ".idc_conv.bias"], prec)
+    else:
+        gates, idc = cond.gates, cond.idc
+    x = F.conv2d(latents, P[p + ".intro.weight"], P[p + ".intro.bias"], padding=1)
+    skips = []
+    for i, n in enumerate((2, 2, 4, 8)):
+        for j in range(n):
+            x = cond_naf_block(P, f"{p}.encoders.{i}.{j}", x, temb, prec)
+        skips.append(x)
+        x = _gemm_conv(x, P[f"{p}.downs.{i}.weight"], P[f"{p}.downs.{i}.bias"], prec, stride=2)
+    for j in range(8):
+        x = cond_naf_block(P, f"{p}.middle_blks.{j}", x, temb, prec)
+    x = x + idc.reshape(B, *x.shape[1:])
+    x = hca_apply(P, p + ".hcas.0", gates[0][0], gates[0][1], x, prec)
+    for i, skip in enumerate(skips[::-1]):
+        x = _up_shuffle(x, P[f"{p}.ups.{i}.0.weight"], 2, prec) + skip
+        for j in range(2):
+            x = cond_naf_block(P, f"{p}.decoders.{i}.{j}", x, temb, prec)
+        x = hca_apply(P, f"{p}.hcas.{i + 1}", gates[i + 1][0], gates[i + 1][1], x, prec)
+    return F.conv2d(x, P[p + ".ending.weight"], P[p + ".ending.bias"], padding=1)
+
+
+def refiner_forward(P, latents, timesteps, cr_face, cr_latent, prec=FP32):
+    """FacialRefiner.forward as written: FPG and IDC recomputed on every call (models/refiner.py:32-38)."""
+    priors = fpg(P, cr_latent, "fpg", prec)
+    id_emb = resnet50(P, cr_face, "idc", prec)
+    return fused_denoiser(P, latents, timesteps, priors, id_emb, prec)
+
+
+# --------------------------------------------------------------------------------------- schedulers
+class _SchedulerBase:
+    """Noise schedule shared by DDIM/DDPM: scaled_linear betas, fp32 cumprod (diffusers 0.32.2
+    semantics; constructor args as at test_refiner.py:166-171 / train_refiner.py:337-348)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02,
+                 beta_schedule="scaled_linear", prediction_type="epsilon",
+                 clip_sample=True, clip_sample_range=1.0):
+        if beta_schedule != "scaled_linear" or prediction_type != "epsilon":
+            raise NotImplementedError("only scaled_linear / epsilon are used by the reference")
+        self.num_train_timesteps = num_train_timesteps
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                                    dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0)          # set_alpha_to_one=True
+        self.clip_sample = clip_sample
+        self.clip_sample_range = clip_sample_range
+        self.timesteps = list(range(num_train_timesteps - 1, -1, -1))
+        self.num_inference_steps = num_train_timesteps
+
+    def set_timesteps(self, n, device=None):
+        """'leading' spacing, steps_offset 0: [i * (T // n)] reversed."""
+        r = self.num_train_timesteps // n
+        self.num_inference_steps = n
+        self.timesteps = [i * r for i in range(n)][::-1]
+
+    def _alpha(self, t):
+        return self.alphas_cumprod[t] if t >= 0 else self.final_alpha_cumprod
+
+
+class _StepOut:
+    def __init__(self, prev_sample, pred_original_sample):
+        self.prev_sample = prev_sample
+        self.pred_original_sample = pred_original_sample
+
+
+class DDIMScheduler(_SchedulerBase):
+    def step(self, eps, t, x, eta=0.0):
+        if eta != 0.0:
+            raise NotImplementedError("the reference only samples with eta=0")
+        t = int(t)
+        t_prev = t - self.num_train_timesteps // self.num_inference_steps
+        a, a_p = self._alpha(t), self._alpha(t_prev)
+        x0 = (x - (1 - a) ** 0.5 * eps) / a ** 0.5
+        if self.clip_sample:
+            x0 = x0.clamp(-self.clip_sample_range, self.clip_sample_range)
+        # use_clipped_model_output=False: eps is not recomputed from the clipped x0
+        return _StepOut(a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps, x0)
+
+
+class DDPMScheduler(_SchedulerBase):
+    """'fixed_small' variance; noise is passed in so runs are reproducible."""
+
+    def step(self, eps, t, x, noise=None):
+        t = int(t)
+        t_prev = t - self.num_train_timesteps // self.num_inference_steps
+        a, a_p = self._alpha(t), self._alpha(t_prev)
+        alpha_t = a / a_p
+        beta_t = 1 - alpha_t
+        x0 = (x - (1 - a) ** 0.5 * eps) / a ** 0.5
+        if self.clip_sample:
+            x0 = x0.clamp(-self.clip_sample_range, self.clip_sample_range)
+        mu = (a_p ** 0.5 * beta_t / (1 - a)) * x0 + (alpha_t ** 0.5 * (1 - a_p) / (1 - a)) * x
+        if t > 0:
+            var = torch.clamp((1 - a_p) / (1 - a) * beta_t, min=1e-20)
+            mu = mu + var ** 0.5 * noise
+        return _StepOut(mu, x0)
+
+
+def step_coefficients(sched, kind):
+    """Per-step scalars in the form the HIP sampler consumes:
+        x0     = clamp((x - c[0]*eps) / c[1], +-c[2])
+        x_prev = c[3]*x0 + c[4]*x + c[5]*eps + c[6]*z
+    One row per entry of sched.timesteps (fp32)."""
+    rows = []
+    r = sched.num_train_timesteps // sched.num_inference_steps
+    clip = float(sched.clip_sample_range) if sched.clip_sample else float("inf")
+    for t in sched.timesteps:
+        a, a_p = sched._alpha(t), sched._alpha(t - r)
+        if kind == "ddim":
+            rows.append([(1 - a) ** 0.5, a ** 0.5, clip, a_p ** 0.5, 0.0, (1 - a_p) ** 0.5, 0.0])
+        else:
+            alpha_t = a / a_p
+            beta_t = 1 - alpha_t
+            sig = torch.clamp((1 - a_p) / (1 - a) * beta_t, min=1e-20) ** 0.5 if t > 0 else 0.0
+            rows.append([(1 - a) ** 0.5, a ** 0.5, clip, a_p ** 0.5 * beta_t / (1 - a),
+                         alpha_t ** 0.5 * (1 - a_p) / (1 - a), 0.0, sig])
+    return torch.tensor([[float(v) for v in row] for row in rows], dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------------------- samplers
+def sample(P, x, cr_face, cr_latent, sched, kind="ddim", noise_fn=None, prec=FP32,
+           as_written=False, id_emb=None, max_steps=None):
+    """The reverse-diffusion loop (test_refiner.py:85-91; canonical train_refiner.py:109-120) in
+    latent space.  as_written=True recomputes FPG+IDC per step exactly like the reference; otherwise
+    the conditioning is hoisted.  `noise_fn(step_index)` supplies z for DDPM."""
+    cond = None if as_written else Conditioning(P, cr_latent, cr_face, id_emb, prec)
+    for i, t in enumerate(sched.timesteps):
+        if max_steps is not None and i >= max_steps:
+            break
+        tb = torch.full((x.shape[0],), t)
+        if as_written:
+            eps = refiner_forward(P, x, tb, cr_face, cr_latent, prec)
+        else:
+            eps = fused_denoiser(P, x, tb, prec=prec, cond=cond)
+        if kind == "ddim":
+            x = sched.step(eps, t, x, eta=0.0).prev_sample
+        else:
+            z = noise_fn(i) if t > 0 else None
+            x = sched.step(eps, t, x, noise=z).prev_sample
+    return x

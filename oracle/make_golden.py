@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from /root/reference).
+
+Runs only in the build container (the reference does not exist on the GPU box and never enters
+this repo).  The reference's `models/denoiser/model.py:4` imports `diffusers.ConfigMixin`, which is
+not installed; it is used purely as an empty attribute bag (model.py:39-41,144-146), so a stub
+module providing `class ConfigMixin: pass` is registered before the import.
+
+Weights and inputs come from hifidiff_amd.synth (regenerable anywhere from one seed); the fixtures
+hold only the reference's OUTPUTS, plus the shapes/tags needed to regenerate the inputs.
+
+The scheduler is NOT reference code (diffusers is absent): the end-to-end fixtures run the
+reference network inside oracle.hifidiff_oracle's restated DDIM/DDPM schedulers, so they pin the
+network-in-the-loop, not the scheduler arithmetic ("parity unpinned" for the scheduler).
+
+Usage:  python oracle/make_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from hifidiff_amd import arch, synth          # noqa: E402
+from oracle import hifidiff_oracle as O       # noqa: E402
+
+
+def import_reference(ref):
+    stub = types.ModuleType("diffusers")
+    stub.ConfigMixin = type("ConfigMixin", (), {})
+    sys.modules["diffusers"] = stub
+    sys.path.insert(0, ref)
+    from models.refiner import FacialRefiner
+    from models.denoiser.conditional_naf import ConditionalNAFBlock
+    from models.denoiser.model import SinusoidalPosEmb
+    from models.fpg.hca import HybridCrossAttention
+    return FacialRefiner, ConditionalNAFBlock, SinusoidalPosEmb, HybridCrossAttention
+
+
+def sub_state(sd, prefix):
+    n = len(prefix) + 1
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix + ".")}
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@torch.no_grad()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--skip-l32", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.manual_seed(0)
+    FacialRefiner, CondBlock, PosEmb, HCA = import_reference(args.ref)
+
+    t0 = time.time()
+    sd = synth.refiner_state_dict(16)
+    net = FacialRefiner(16).eval()
+    net.load_state_dict(sd, strict=True)
+    print(f"reference model ready in {time.time() - t0:.1f}s")
+
+    # ---- 1. one ConditionalNAFBlock per level (conditional_naf.py:108-136) ----
+    out = {}
+    temb = T(synth.randn("blk_temb", (1, 512)))
+    names = ["encoders.0.0", "encoders.1.0", "encoders.2.0", "encoders.3.0", "middle_blks.0"]
+    for l, (c, h) in enumerate(arch.naf_levels(16)):
+        blk = CondBlock(c, 512).eval()
+        blk.load_state_dict(sub_state(sd, "denoiser." + names[l]), strict=True)
+        x = T(synth.randn(f"blk_in/{l}", (1, c, h, h)))
+        y, _ = blk([x, temb])
+        out[f"out{l}"] = y.numpy()
+    np.savez_compressed(os.path.join(args.out, "cond_naf_blocks.npz"), **out)
+
+    # ---- 2. HybridCrossAttention at every resolution (hca.py:25-48) ----
+    out = {}
+    for i, (c, h) in enumerate(arch.naf_levels(16)[::-1]):
+        m = HCA(c).eval()
+        m.load_state_dict(sub_state(sd, f"denoiser.hcas.{i}"), strict=True)
+        f_g = T(synth.randn(f"hca_fg/{i}", (1, c, h, h)))
+        f_d = T(synth.randn(f"hca_fd/{i}", (1, c, h, h)))
+        out[f"out{i}"] = m(f_g, f_d).numpy()
+        out[f"wc{i}"] = m.channel_cross_attention(f_g).numpy()
+        out[f"ws{i}"] = m.spatial_cross_attention(f_g).numpy()
+    np.savez_compressed(os.path.join(args.out, "hca.npz"), **out)
+
+    # ---- 3. sinusoidal embedding + time_mlp (model.py:22-29,152-157) ----
+    ts = torch.tensor([0.0, 1.0, 500.0, 999.0])
+    np.savez_compressed(os.path.join(args.out, "time_embedding.npz"),
+                        t=ts.numpy(), posemb=PosEmb(128)(ts).numpy(),
+                        temb=net.denoiser.time_mlp(ts).numpy())
+
+    # ---- 4./5. FPG priors and ResNet-50 embedding, B=1 ----
+    x1, crl1, crf1 = synth.sample_inputs(1, 16)
+    pri = net.fpg(crl1)
+    np.savez_compressed(os.path.join(args.out, "fpg_priors.npz"),
+                        **{f"prior{i}": p.numpy() for i, p in enumerate(pri)})
+    np.savez_compressed(os.path.join(args.out, "idc_embedding.npz"), emb=net.idc(crf1).numpy())
+
+    # ---- 6. full refiner eps, B=2, a few timesteps (refiner.py:32-38) ----
+    x2, crl2, crf2 = synth.sample_inputs(2, 16)
+    out = {}
+    for t in (980, 500, 0):
+        out[f"eps_t{t}"] = net(x2, torch.full((2,), t), crf2, crl2).sample.numpy()
+    # mixed per-face timesteps and the scalar form accepted by model.py:218-229
+    out["eps_tmixed"] = net(x2, torch.tensor([37, 861]), crf2, crl2).sample.numpy()
+    pri2 = net.fpg(crl2)
+    emb2 = net.idc(crf2)
+    out["eps_scalar_t250"] = net.denoiser(x2, 250, pri2, emb2).sample.numpy()
+    np.savez_compressed(os.path.join(args.out, "refiner_eps_L16.npz"), **out)
+
+    # ---- 7. 50-step DDIM, clip 3.0, as written (test_refiner.py:85-91,166-171), B=2 ----
+    t0 = time.time()
+    sch = O.DDIMScheduler(clip_sample=True, clip_sample_range=3.0)
+    sch.set_timesteps(50)
+    lat = x2.clone()
+    for t in sch.timesteps:
+        eps = net(lat, torch.full((2,), t), crf2, crl2).sample
+        lat = sch.step(eps, t, lat, eta=0.0).prev_sample
+    np.savez_compressed(os.path.join(args.out, "ddim50_L16.npz"), final=lat.numpy())
+    print(f"ddim50 {time.time() - t0:.1f}s  |x|max={lat.abs().max():.3f}")
+
+    # ---- 8. first 20 steps of the 1000-step DDPM (clip 3.0) with committed-seed noise, B=2 ----
+    t0 = time.time()
+    sch = O.DDPMScheduler(clip_sample=True, clip_sample_range=3.0)
+    lat = x2.clone()
+    for i, t in enumerate(sch.timesteps[:20]):
+        eps = net(lat, torch.full((2,), t), crf2, crl2).sample
+        z = T(np.stack([synth.ddpm_noise(i, b, 16) for b in range(2)]))
+        lat = sch.step(eps, t, lat, noise=z).prev_sample
+    np.savez_compressed(os.path.join(args.out, "ddpm20_L16.npz"), final=lat.numpy())
+    print(f"ddpm20 {time.time() - t0:.1f}s  |x|max={lat.abs().max():.3f}")
+
+    # ---- 9. latent 32 (FacialRefiner(32): idc_conv 2048->8192, mid at 2x2), B=1 ----
+    if not args.skip_l32:
+        del net
+        sd32 = synth.refiner_state_dict(32)
+        net32 = FacialRefiner(32).eval()
+        net32.load_state_dict(sd32, strict=True)
+        x, crl, crf = synth.sample_inputs(1, 32)
+        e = net32(x, torch.full((1,), 500), crf, crl).sample
+        np.savez_compressed(os.path.join(args.out, "refiner_eps_L32.npz"), eps_t500=e.numpy())
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

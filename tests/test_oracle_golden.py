@@ -1,0 +1,112 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(oracle/make_golden.py).  fp32 mode must reproduce the reference to fp32 noise (it is in fact
+bit-identical on the machine that generated the fixtures); the bf16-emulation mode must stay within
+the bf16 tolerance SURVEY §8d states (single eps rel-L2 <= 1e-2, 50-step DDIM PSNR >= 40 dB)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, psnr, rel_l2
+from hifidiff_amd import arch, synth
+from oracle import hifidiff_oracle as O
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+TOL32 = 2e-6   # fp32 oracle vs reference (different BLAS threading may reorder sums)
+BLOCKS = ["encoders.0.0", "encoders.1.0", "encoders.2.0", "encoders.3.0", "middle_blks.0"]
+
+
+def test_time_embedding(weights16):
+    g = golden("time_embedding.npz")
+    t = T(g["t"])
+    assert rel_l2(O.sinusoidal_embedding(t), g["posemb"]) <= TOL32
+    assert rel_l2(O.time_embedding(weights16, t), g["temb"]) <= TOL32
+
+
+@pytest.mark.parametrize("level", range(5))
+def test_cond_naf_block(weights16, level):
+    g = golden("cond_naf_blocks.npz")
+    c, h = arch.naf_levels(16)[level]
+    x = T(synth.randn(f"blk_in/{level}", (1, c, h, h)))
+    temb = T(synth.randn("blk_temb", (1, 512)))
+    p = "denoiser." + BLOCKS[level]
+    assert rel_l2(O.cond_naf_block(weights16, p, x, temb), g[f"out{level}"]) <= TOL32
+    assert rel_l2(O.cond_naf_block(weights16, p, x, temb, O.BF16), g[f"out{level}"]) <= 2e-3
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_hca(weights16, i):
+    g = golden("hca.npz")
+    c, h = arch.naf_levels(16)[::-1][i]
+    fg = T(synth.randn(f"hca_fg/{i}", (1, c, h, h)))
+    fd = T(synth.randn(f"hca_fd/{i}", (1, c, h, h)))
+    p = f"denoiser.hcas.{i}"
+    w_c, w_s = O.hca_gates(weights16, p, fg)
+    assert rel_l2(w_c, g[f"wc{i}"]) <= TOL32 and rel_l2(w_s, g[f"ws{i}"]) <= TOL32
+    assert rel_l2(O.hca(weights16, p, fg, fd), g[f"out{i}"]) <= TOL32
+    assert rel_l2(O.hca(weights16, p, fg, fd, O.BF16), g[f"out{i}"]) <= 1e-2
+
+
+def test_fpg_and_idc(weights16):
+    _, crl, crf = synth.sample_inputs(1, 16)
+    g = golden("fpg_priors.npz")
+    for prec, tol in ((O.FP32, TOL32), (O.BF16, 2e-2)):
+        for i, p in enumerate(O.fpg(weights16, crl, "fpg", prec)):
+            assert rel_l2(p, g[f"prior{i}"]) <= tol, (prec.emulate, i)
+    e = golden("idc_embedding.npz")["emb"]
+    assert rel_l2(O.resnet50(weights16, crf), e) <= TOL32
+    assert rel_l2(O.resnet50(weights16, crf, "idc", O.BF16), e) <= 1e-2
+
+
+def test_refiner_eps(weights16):
+    x, crl, crf = synth.sample_inputs(2, 16)
+    g = golden("refiner_eps_L16.npz")
+    for t in (980, 500, 0):
+        assert rel_l2(O.refiner_forward(weights16, x, torch.full((2,), t), crf, crl), g[f"eps_t{t}"]) <= TOL32
+    assert rel_l2(O.refiner_forward(weights16, x, torch.tensor([37, 861]), crf, crl), g["eps_tmixed"]) <= TOL32
+    cond = O.Conditioning(weights16, crl, crf)
+    assert rel_l2(O.fused_denoiser(weights16, x, 250, cond=cond), g["eps_scalar_t250"]) <= TOL32
+    e = O.fused_denoiser(weights16, x, torch.full((2,), 500), cond=O.Conditioning(weights16, crl, crf, prec=O.BF16),
+                         prec=O.BF16)
+    assert rel_l2(e, g["eps_t500"]) <= 1e-2
+
+
+def test_ddim50_and_ddpm20(weights16):
+    x, crl, crf = synth.sample_inputs(2, 16)
+    sch = O.DDIMScheduler(clip_sample=True, clip_sample_range=3.0)
+    sch.set_timesteps(50)
+    assert sch.timesteps[0] == 980 and sch.timesteps[-1] == 0
+    lat = O.sample(weights16, x, crf, crl, sch, "ddim")
+    gd = golden("ddim50_L16.npz")["final"]
+    assert float((lat - T(gd)).abs().max()) <= 1e-4
+    sch = O.DDPMScheduler(clip_sample=True, clip_sample_range=3.0)
+    noise = lambda i: T(np.stack([synth.ddpm_noise(i, b, 16) for b in range(2)]))  # noqa: E731
+    lat = O.sample(weights16, x, crf, crl, sch, "ddpm", noise_fn=noise, max_steps=20)
+    assert float((lat - T(golden("ddpm20_L16.npz")["final"])).abs().max()) <= 1e-4
+    lat = O.sample(weights16, x, crf, crl, sch, "ddpm", noise_fn=noise, max_steps=20, prec=O.BF16)
+    assert psnr(lat, golden("ddpm20_L16.npz")["final"]) >= 40.0
+
+
+def test_scheduler_formulas():
+    """Known values of the restated diffusers arithmetic (parity unpinned: no reference fixture)."""
+    s = O.DDIMScheduler()
+    assert abs(float(s.betas[0]) - 1e-4) < 1e-9 and abs(float(s.betas[-1]) - 0.02) < 1e-7
+    ab = np.cumprod(1.0 - np.linspace(1e-4 ** 0.5, 0.02 ** 0.5, 1000, dtype=np.float64) ** 2)
+    assert np.allclose(s.alphas_cumprod.numpy(), ab, rtol=2e-5)     # independent float64 evaluation
+    s.set_timesteps(250)
+    assert s.timesteps[:2] == [996, 992] and s.timesteps[-1] == 0
+    # DDIM with eps = 0 and no clipping scales x by sqrt(a_prev/a)
+    s = O.DDIMScheduler(clip_sample=False)
+    s.set_timesteps(50)
+    x = torch.ones(1, 4, 2, 2)
+    out = s.step(torch.zeros_like(x), 980, x).prev_sample
+    assert torch.allclose(out, x * (s.alphas_cumprod[960] / s.alphas_cumprod[980]) ** 0.5, rtol=1e-6)
+    # coefficient form used by the HIP sampler reproduces step()
+    d = O.DDPMScheduler(clip_sample=True, clip_sample_range=3.0)
+    c = O.step_coefficients(d, "ddpm")
+    x, e, z = torch.randn(3, 1, 4, 4, 4).unbind(0)
+    for i in (0, 500, 999):
+        t = d.timesteps[i]
+        ref = d.step(e, t, x, noise=z).prev_sample
+        x0 = ((x - c[i, 0] * e) / c[i, 1]).clamp(-c[i, 2], c[i, 2])
+        got = c[i, 3] * x0 + c[i, 4] * x + c[i, 5] * e + c[i, 6] * z
+        assert torch.allclose(got, ref, atol=2e-5)
