@@ -1,0 +1,395 @@
+// hd_kernels.hpp — the non-GEMM kernels of the refiner path (gfx950).  All activations are
+// channels-last fp32 [rows = (face, y, x)][C] unless stated; see DESIGN.md for the buffer map.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hd_gemm.hpp"
+
+namespace hd {
+
+// Device-resident loop state read by the captured per-step graph (so one graph serves every step).
+struct StepState {
+    int step;                 // index into the schedule; incremented by the first kernel of a step
+    int pad;
+    const float* noise;       // [n_steps][n_elems] or NULL -> Philox
+    unsigned long long seed;
+};
+
+// ----------------------------------------------------------------------------------- weight packing
+// fp32 conv/linear weight [N][Cin][KH][KW] -> bf16 MFMA B-fragment order [nt][kstep][lane][8] with
+// k = tap*Cin_pad + c, optional per-output-channel scale (folded BatchNorm), optional centre-tap
+// slice (3x3 conv on a 1x1 map: only the centre tap ever sees data), optional output permutation
+// n' = pos*Cg + c  <-  n = c*S2 + pos  (idc_conv: (B,2048*s*s,1,1) viewed as (B,2048,s,s), model.py:246).
+struct PackP {
+    const float* src; uint4* dst;
+    int N, Cin, Cin_pad, KH, KW, ntaps, centre_only, S2, Kp, nt_total;
+    const float* nscale;
+};
+__global__ void pack_weight_kernel(const PackP p) {
+    const int ksteps = p.Kp >> 4;
+    const size_t total = (size_t)p.nt_total * ksteps * 64;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63);
+        const size_t tk = e >> 6;
+        const int ks = (int)(tk % ksteps), nt = (int)(tk / ksteps);
+        const int np = nt * 32 + (lane & 31);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + 8 * (lane >> 5) + j;
+            const int tap = k / p.Cin_pad, c = k - tap * p.Cin_pad;
+            float x = 0.f;
+            if (np < p.N && tap < p.ntaps && c < p.Cin) {
+                int n = np;
+                if (p.S2 > 1) { const int cg = p.N / p.S2; n = (np % cg) * p.S2 + np / cg; }
+                int ky, kx;
+                if (p.centre_only) { ky = p.KH >> 1; kx = p.KW >> 1; }
+                else { ky = tap / p.KW; kx = tap - ky * p.KW; }
+                x = p.src[(((size_t)n * p.Cin + c) * p.KH + ky) * p.KW + kx];
+                if (p.nscale) x *= p.nscale[n];
+            }
+            v[j] = x;
+        }
+        p.dst[e] = pack8(v);
+    }
+}
+
+// ----------------------------------------------------------------------------------- intro / ending
+// intro: Conv2d(4,128,3,pad 1) on the NCHW latent -> channels-last fp32 (models/denoiser/model.py:159-167,235).
+// fp32 FMA (K = 36 is too small for MFMA).  The first thread also advances the loop's step counter.
+__global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict__ lat, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ out,
+                                                          int B, int L, StepState* st, int advance) {
+    __shared__ float wt[36][128];
+    __shared__ float patch[16][36];
+    if (advance && blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;
+    for (int i = threadIdx.x; i < 36 * 128; i += 256) {
+        const int co = i / 36, r = i - co * 36;           // w[co][ci][ky][kx], r = ci*9 + tap
+        wt[r][co] = w[i];
+    }
+    const int M = B * L * L;
+    const int p0 = blockIdx.x * 16;
+    for (int i = threadIdx.x; i < 16 * 36; i += 256) {
+        const int pl = i / 36, r = i - pl * 36;
+        const int ci = r / 9, tap = r - ci * 9;
+        const int pix = p0 + pl;
+        float v = 0.f;
+        if (pix < M) {
+            const int bb = pix / (L * L), rem = pix - bb * L * L;
+            const int y = rem / L + tap / 3 - 1, x = rem % L + tap % 3 - 1;
+            if (y >= 0 && y < L && x >= 0 && x < L) v = lat[((size_t)(bb * 4 + ci) * L + y) * L + x];
+        }
+        patch[pl][r] = v;
+    }
+    __syncthreads();
+    const int co = threadIdx.x & 127;
+    for (int pl = threadIdx.x >> 7; pl < 16; pl += 2) {
+        const int pix = p0 + pl;
+        if (pix >= M) break;
+        float acc = b[co];
+#pragma unroll
+        for (int r = 0; r < 36; ++r) acc += patch[pl][r] * wt[r][co];
+        out[(size_t)pix * 128 + co] = acc;
+    }
+}
+
+// ending: Conv2d(128,4,3,pad 1) channels-last fp32 -> NCHW eps (models/denoiser/model.py:168-176,261).
+// One wave per pixel, lanes over input channels, wave reduction.
+__global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ eps,
+                                                           int B, int L) {
+    __shared__ float wt[9][4][128];                       // [tap][co][ci]
+    for (int i = threadIdx.x; i < 4 * 128 * 9; i += 256) {
+        const int co = i / (128 * 9), r = i - co * 128 * 9, ci = r / 9, tap = r - ci * 9;
+        wt[tap][co][ci] = w[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int M = B * L * L;
+    const int pix = blockIdx.x * 4 + wave;
+    if (pix >= M) return;
+    const int bb = pix / (L * L), rem = pix - bb * L * L, y = rem / L, x = rem - y * L;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy < 0 || yy >= L || xx < 0 || xx >= L) continue;
+        const float* xp = X + ((size_t)(bb * L + yy) * L + xx) * 128;
+        const float v0 = xp[lane], v1 = xp[lane + 64];
+        a0 += v0 * wt[tap][0][lane] + v1 * wt[tap][0][lane + 64];
+        a1 += v0 * wt[tap][1][lane] + v1 * wt[tap][1][lane + 64];
+        a2 += v0 * wt[tap][2][lane] + v1 * wt[tap][2][lane + 64];
+        a3 += v0 * wt[tap][3][lane] + v1 * wt[tap][3][lane + 64];
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    if (lane == 0) {
+        const size_t o = ((size_t)bb * 4 * L + y) * L + x, cs = (size_t)L * L;
+        eps[o] = a0 + b[0]; eps[o + cs] = a1 + b[1]; eps[o + 2 * cs] = a2 + b[2]; eps[o + 3 * cs] = a3 + b[3];
+    }
+}
+
+// ----------------------------------------------------------------------- depthwise 3x3 + gate + pool
+// conv2 (depthwise 3x3, pad 1) -> SimpleGate -> G (bf16) and the SCA global average pool
+// (conditional_naf.py:116-119 / naf.py:109-112).  T1 is the fp32 conv1 output [rows][2C].
+// grid (C/32, faces); a workgroup owns one face x 32 gate channels, so the pooled mean is complete
+// without atomics.
+__global__ __launch_bounds__(256) void dwconv_gate_pool_kernel(const float* __restrict__ T1, const float* __restrict__ w2,
+                                                                const float* __restrict__ b2,
+                                                                unsigned short* __restrict__ G, float* __restrict__ pooled,
+                                                                int H, int W, int C) {
+    __shared__ float red[8][32];
+    const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int pg = threadIdx.x >> 5;
+    const int face = blockIdx.y;
+    const int HW = H * W, C2 = 2 * C;
+    float wa[9], wb[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wa[t] = w2[(size_t)j * 9 + t]; wb[t] = w2[(size_t)(j + C) * 9 + t]; }
+    const float ba = b2[j], bb = b2[j + C];
+    const float* base = T1 + (size_t)face * HW * C2;
+    float sum = 0.f;
+    for (int p = pg; p < HW; p += 8) {
+        const int y = p / W, x = p - y * W;
+        float u1 = ba, u2 = bb;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const float* q = base + (size_t)(yy * W + xx) * C2;
+            u1 += wa[t] * q[j];
+            u2 += wb[t] * q[j + C];
+        }
+        const float g = u1 * u2;
+        G[((size_t)face * HW + p) * C + j] = f32_to_bf16_bits(g);
+        sum += g;
+    }
+    red[pg][threadIdx.x & 31] = sum;
+    __syncthreads();
+    if (pg == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += red[i][threadIdx.x];
+        pooled[(size_t)face * C + j] = s / (float)HW;
+    }
+}
+
+// -------------------------------------------------------------------------------------- FiLM path
+// sinusoidal embedding: [sin(t f_k), cos(t f_k)], k < 64 (models/denoiser/model.py:22-29).
+// f_k comes from the host (expf in fp32, like torch.exp on a float32 tensor).
+__global__ void time_embed_kernel(const float* __restrict__ t, const float* __restrict__ freq, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 64) return;
+    const int r = i >> 6, k = i & 63;
+    const float a = t[r] * freq[k];
+    out[(size_t)r * 128 + k] = sinf(a);
+    out[(size_t)r * 128 + 64 + k] = cosf(a);
+}
+
+// out[m][n] = bias[n] + sum_k in'[m][k] W[n][k], in' = in[m][k]*in[m][k+K] when GATE_IN (SimpleGate on
+// the input).  fp32 FMA: time_mlp and the per-block FiLM Linear(256,4C) stay in fp32
+// (models/denoiser/model.py:152-157, conditional_naf.py:18-22).  64x64 tile, 4x4 per thread.
+template <bool GATE_IN>
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ in, int ldin, const float* __restrict__ Wt,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                          int M, int N, int K) {
+    __shared__ float sa[16][65];
+    __shared__ float sb[16][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+            const int r = i >> 4, kk = i & 15;
+            float a = 0.f, b = 0.f;
+            if (m0 + r < M && k0 + kk < K) {
+                a = in[(size_t)(m0 + r) * ldin + k0 + kk];
+                if (GATE_IN) a *= in[(size_t)(m0 + r) * ldin + K + k0 + kk];
+            }
+            if (n0 + r < N && k0 + kk < K) b = Wt[(size_t)(n0 + r) * K + k0 + kk];
+            sa[kk][r] = a; sb[kk][r] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sa[kk][ty * 4 + i]; b[i] = sb[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < M && n < N) out[(size_t)m * ldo + n] = acc[i][j] + bias[n];
+        }
+}
+
+// Fold LayerNorm2d's affine into FiLM, in place on the raw Linear output of one block:
+//   raw  = [shift_att, scale_att, shift_ffn, scale_ffn]            (conditional_naf.py:110)
+//   out  = [b1*(1+scale_att)+shift_att, w1*(1+scale_att), b2*(1+scale_ffn)+shift_ffn, w2*(1+scale_ffn)]
+// ln holds [b1, w1, b2, w2] at the same offsets.  grid (ceil(C/256), n_blocks, rows).
+struct FilmBlock { int off, C; };
+__global__ void film_fold_kernel(float* __restrict__ film, const float* __restrict__ ln, const FilmBlock* __restrict__ blocks,
+                                 int film_total) {
+    const FilmBlock fb = blocks[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= fb.C) return;
+    float* f = film + (size_t)blockIdx.z * film_total + fb.off;
+    const float* l = ln + fb.off;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float shift = f[2 * h * fb.C + c], scale = f[(2 * h + 1) * fb.C + c];
+        const float lb = l[2 * h * fb.C + c], lw = l[(2 * h + 1) * fb.C + c];
+        f[2 * h * fb.C + c] = lb * (scale + 1.0f) + shift;
+        f[(2 * h + 1) * fb.C + c] = lw * (scale + 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------- scheduler
+// Philox4x32-10 (Salmon et al. 2011), counter (elem, step, 0, 0), key (seed lo, seed hi); two
+// Box-Muller normals per call, the first is used.  Restated identically in tests (numpy).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned* o) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned step, unsigned elem) {
+    unsigned o[4];
+    philox4x32_10(elem, step, 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+    const float u1 = ((float)(o[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);               // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// x0 = clamp((x - c0*eps)/c1, +-c2);  x <- c3*x0 + c4*x + c5*eps + c6*z      (hd_schedule in the C-ABI)
+__global__ void sched_step_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ coef,
+                                  const StepState* __restrict__ st, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int step = st->step;
+    const float* c = coef + (size_t)step * 7;
+    const float xv = x[i], e = eps[i];
+    float x0 = (xv - c[0] * e) / c[1];
+    x0 = fminf(fmaxf(x0, -c[2]), c[2]);
+    float r = c[3] * x0 + c[4] * xv + c[5] * e;
+    if (c[6] != 0.f) {
+        const float z = st->noise ? st->noise[(size_t)step * n + i] : philox_normal(st->seed, (unsigned)step, (unsigned)i);
+        r += c[6] * z;
+    }
+    x[i] = r;
+}
+
+struct Coef7 { float c[7]; };
+__global__ void sched_step_direct_kernel(float* __restrict__ x, const float* __restrict__ eps, const Coef7 k,
+                                         const float* __restrict__ noise, unsigned long long seed, int step, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[i], e = eps[i];
+    float x0 = (xv - k.c[0] * e) / k.c[1];
+    x0 = fminf(fmaxf(x0, -k.c[2]), k.c[2]);
+    float r = k.c[3] * x0 + k.c[4] * xv + k.c[5] * e;
+    if (k.c[6] != 0.f) r += k.c[6] * (noise ? noise[i] : philox_normal(seed, (unsigned)step, (unsigned)i));
+    x[i] = r;
+}
+
+// ------------------------------------------------------------------------------- pooling / layout
+// channels-last fp32 -> NCHW fp32 (priors handed out by hd_fpg)
+__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int p = (int)(i % HW);
+    const size_t r = i / HW;
+    const int c = (int)(r % C);
+    const size_t b = r / C;
+    out[i] = in[(b * HW + p) * C + c];
+}
+
+// avg + max pool over the face: HCA channel gate input (models/fpg/hca.py:34-36).  X fp32 [B][HW][C].
+__global__ void pool_avgmax_kernel(const float* __restrict__ X, float* __restrict__ out, int HW, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* p = X + (size_t)blockIdx.y * HW * C + c;
+    float s = 0.f, m = -3.402823466e38f;
+    for (int i = 0; i < HW; ++i) { const float v = p[(size_t)i * C]; s += v; m = fmaxf(m, v); }
+    out[(size_t)blockIdx.y * C + c] = s / (float)HW + m;
+}
+
+// out[row] = sigmoid(dot(Hd[row], w) + bias): spatial gate's Conv2d(C/2,1,1)+BN (folded)+Sigmoid
+// (models/fpg/hca.py:16-18).  One wave per row, fp32.
+__global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(const float* __restrict__ Hd, const float* __restrict__ w, float bias,
+                                                              float* __restrict__ out, int M, int K) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += Hd[(size_t)row * K + k] * w[k];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = 1.0f / (1.0f + expf(-(s + bias)));
+}
+
+// NCHW fp32 -> channels-last fp32 (priors handed in by hd_prepare_from_priors)
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const size_t r = i / C;
+    const int p = (int)(r % HW);
+    const size_t b = r / HW;
+    out[i] = in[(b * C + c) * HW + p];
+}
+
+// cr_face NCHW fp32 [B,3,H,W] -> channels-last bf16 padded to 8 channels (ResNet conv1 input)
+__global__ void nchw3_to_nhwc8_bf16_kernel(const float* __restrict__ in, uint4* __restrict__ out, int HW, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const size_t b = i / HW, p = i - b * HW;
+    float v[8] = {in[(b * 3 + 0) * HW + p], in[(b * 3 + 1) * HW + p], in[(b * 3 + 2) * HW + p], 0, 0, 0, 0, 0};
+    out[i] = pack8(v);
+}
+
+// MaxPool2d(3, stride 2, pad 1) on channels-last bf16 (models/idc/model.py:112,124)
+__global__ void maxpool3x3s2_bf16_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+                                         int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float m = -3.402823466e38f;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            const int y = oy * 2 - 1 + ky, x = ox * 2 - 1 + kx;
+            if (y < 0 || y >= H || x < 0 || x >= W) continue;
+            m = fmaxf(m, bf16_bits_to_f32(in[(((size_t)b * H + y) * W + x) * C + c]));
+        }
+    out[i] = f32_to_bf16_bits(m);
+}
+
+// AdaptiveAvgPool2d(1) on channels-last bf16 -> fp32 [B][C] (models/idc/model.py:131)
+__global__ void avgpool_bf16_kernel(const unsigned short* __restrict__ in, float* __restrict__ out, int HW, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const unsigned short* p = in + (size_t)blockIdx.y * HW * C + c;
+    float s = 0.f;
+    for (int i = 0; i < HW; ++i) s += bf16_bits_to_f32(p[(size_t)i * C]);
+    out[(size_t)blockIdx.y * C + c] = s / (float)HW;
+}
+
+}  // namespace hd

@@ -1,0 +1,1209 @@
+// hd_lib.hip — host side of libhifidiff_hip.so: context, weight ingest (fold + pack), the launch
+// program of one denoiser evaluation, the once-per-batch conditioning prologue, and the graph-replayed
+// reverse-diffusion loop.  C-ABI in include/hifidiff_hip.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/hifidiff_hip.h"
+#include "hd_gemm.hpp"
+#include "hd_kernels.hpp"
+
+using namespace hd;
+
+namespace {
+
+constexpr int WIDTH = 128;
+constexpr int FILM_IN = 256;                  // SimpleGate(512) -> 256 (conditional_naf.py:19)
+constexpr size_t HOST_MIRROR_MAX = 1 << 16;   // small tensors keep a host copy (BN folding etc.)
+
+struct RawTensor {
+    std::vector<int64_t> shape;
+    size_t numel = 0;
+    float* dev = nullptr;
+    std::vector<float> host;                  // filled when numel <= HOST_MIRROR_MAX
+};
+
+struct PackedW {
+    uint4* w = nullptr;
+    int N = 0, K = 0, Kp = 0, nt_total = 0;   // K = ntaps*Cin_pad
+    const float* bias = nullptr;              // device fp32 (may be folded)
+};
+
+struct BlockW {
+    std::string name;
+    int C = 0, film_off = -1;
+    PackedW conv1, conv3, sca, conv4, conv5;
+    const float *dw_w = nullptr, *dw_b = nullptr, *beta = nullptr, *gamma = nullptr;
+};
+
+struct HcaW {
+    int C = 0;
+    PackedW mlp0, mlp2, sp0, fused;
+    const float* sp3_w = nullptr;             // folded [C/2]
+    float sp3_b = 0.f;
+    bool centre_only = false;
+};
+
+struct ResConv { PackedW w; int cin, cout, k, stride, pad; };
+struct ResBlock { ResConv c1, c2, c3, ds; bool has_ds = false; };
+
+enum LdKind { LK_F32, LK_LN, LK_BF16, LK_BF16S, LK_CONV_F32, LK_CONV_F32G, LK_CONV_BF16 };
+enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16 };
+
+struct Op {
+    std::string name;
+    std::function<hipError_t(hipStream_t)> run;
+    const void* out = nullptr;       // output buffer of the launch (introspection only)
+    size_t out_elems = 0;
+    int out_bf16 = 0;
+};
+
+struct Level { int C, H, M; float *X, *Y, *T1, *pooled, *S; unsigned short* G; };
+
+}  // namespace
+
+static std::string g_create_error;
+
+struct hd_ctx {
+    int L = 16, device = 0, S = 1;            // S = L/16
+    std::string err;
+    std::unordered_map<std::string, RawTensor> raw;
+    std::vector<void*> allocs;
+    bool finalized = false;
+
+    // weights
+    std::vector<BlockW> den_blocks, fpg_blocks;       // execution order
+    std::map<std::string, int> den_block_index;
+    PackedW den_down[4], den_up[4], fpg_down[4], fpg_convs[5], idc_conv;
+    HcaW hca[5];
+    ResConv res_conv1;
+    std::vector<ResBlock> res_blocks;
+    int film_total = 0;
+    float *film_W = nullptr, *film_b = nullptr, *ln_pack = nullptr, *fpg_ln_pack = nullptr;
+    FilmBlock* film_blocks_dev = nullptr;
+    float* freq_dev = nullptr;
+    int64_t weight_bytes_per_step = 0;
+    double flops_per_face_step = 0.0;
+
+    // batch-dependent workspace
+    int B = 0;
+    Level lv[5];
+    float *lat = nullptr, *eps = nullptr, *prior[5] = {}, *gate_c[5] = {}, *gate_s[5] = {}, *idc_term = nullptr;
+    float *id_emb = nullptr, *pool_tmp = nullptr, *mlp_tmp = nullptr, *sp_tmp = nullptr;
+    unsigned short* res_buf[4] = {};
+    uint4* face8 = nullptr;
+    float* slab = nullptr;
+    size_t slab_bytes = 0;
+    unsigned* counters = nullptr;
+    bool prepared = false;
+
+    // FiLM / schedule
+    float *t_dev = nullptr, *temb_a = nullptr, *temb_b = nullptr, *temb_c = nullptr, *film_table = nullptr;
+    int film_rows_cap = 0;
+    int film_face_stride = 0, film_step_stride = 0;
+    float* coef_dev = nullptr;
+    int coef_cap = 0;
+    StepState* step_state = nullptr;
+    int advance = 0;
+
+    // program
+    std::vector<Op> program;                 // one denoiser evaluation (lat -> eps)
+    std::vector<Op> prep_program;            // the most recent conditioning prologue
+    int op_limit = -1, prep_limit = -1;
+    hipGraphExec_t graph_exec = nullptr;
+    const float* graph_film = nullptr;
+    int graph_B = 0;
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_loop_ms = 0.0;
+    int last_steps = 0;
+    std::map<std::string, std::pair<void*, std::pair<size_t, int>>> dbg;   // name -> (ptr, (elems, is_bf16))
+};
+
+#define HD_FAIL(ctx, code, ...)                                   \
+    do {                                                          \
+        char _b[512];                                             \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                    \
+        (ctx)->err = _b;                                          \
+        return (code);                                            \
+    } while (0)
+#define HIPCHECK(ctx, expr)                                                                         \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) HD_FAIL(ctx, HD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+namespace {
+
+template <class T>
+int dev_alloc(hd_ctx* c, T** out, size_t count) {
+    void* p = nullptr;
+    HIPCHECK(c, hipMalloc(&p, count * sizeof(T) + 256));
+    c->allocs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return HD_OK;
+}
+void dev_free(hd_ctx* c, void* p) {
+    if (!p) return;
+    for (auto& a : c->allocs)
+        if (a == p) { a = nullptr; break; }
+    (void)hipFree(p);
+}
+
+const RawTensor* find_raw(hd_ctx* c, const std::string& n) {
+    auto it = c->raw.find(n);
+    return it == c->raw.end() ? nullptr : &it->second;
+}
+
+// ------------------------------------------------------------------------------ manifest (strict load)
+// Same keys/shapes as FacialRefiner(latent_res).state_dict() — mirrors hifidiff_amd/arch.py.
+using Shape = std::vector<int64_t>;
+void m_conv(std::vector<std::pair<std::string, Shape>>& m, const std::string& n, int co, int ci, int kh, int kw, bool bias = true) {
+    m.push_back({n + ".weight", {co, ci, kh, kw}});
+    if (bias) m.push_back({n + ".bias", {co}});
+}
+void m_lin(std::vector<std::pair<std::string, Shape>>& m, const std::string& n, int co, int ci) {
+    m.push_back({n + ".weight", {co, ci}});
+    m.push_back({n + ".bias", {co}});
+}
+void m_bn(std::vector<std::pair<std::string, Shape>>& m, const std::string& n, int c) {
+    m.push_back({n + ".weight", {c}}); m.push_back({n + ".bias", {c}});
+    m.push_back({n + ".running_mean", {c}}); m.push_back({n + ".running_var", {c}});
+    m.push_back({n + ".num_batches_tracked", {}});
+}
+void m_naf(std::vector<std::pair<std::string, Shape>>& m, const std::string& p, int c, bool film) {
+    m.push_back({p + ".beta", {1, c, 1, 1}}); m.push_back({p + ".gamma", {1, c, 1, 1}});
+    if (film) m_lin(m, p + ".mlp.1", 4 * c, FILM_IN);
+    m_conv(m, p + ".conv1", 2 * c, c, 1, 1);
+    m_conv(m, p + ".conv2", 2 * c, 1, 3, 3);
+    m_conv(m, p + ".conv3", c, c, 1, 1);
+    m_conv(m, p + ".sca.1", c, c, 1, 1);
+    m_conv(m, p + ".conv4", 2 * c, c, 1, 1);
+    m_conv(m, p + ".conv5", c, c, 1, 1);
+    for (const char* n : {".norm1", ".norm2"}) { m.push_back({p + n + ".weight", {c}}); m.push_back({p + n + ".bias", {c}}); }
+}
+std::vector<std::pair<std::string, Shape>> build_manifest(int L) {
+    std::vector<std::pair<std::string, Shape>> m;
+    const int enc[4] = {2, 2, 4, 8}, res_layers[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+    // idc
+    m_conv(m, "idc.conv1", 64, 3, 7, 7, false); m_bn(m, "idc.batch_norm1", 64);
+    int cin = 64;
+    for (int li = 0; li < 4; ++li)
+        for (int b = 0; b < res_layers[li]; ++b) {
+            std::string q = "idc.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            m_conv(m, q + ".conv1", planes[li], cin, 1, 1); m_bn(m, q + ".batch_norm1", planes[li]);
+            m_conv(m, q + ".conv2", planes[li], planes[li], 3, 3); m_bn(m, q + ".batch_norm2", planes[li]);
+            m_conv(m, q + ".conv3", planes[li] * 4, planes[li], 1, 1); m_bn(m, q + ".batch_norm3", planes[li] * 4);
+            if (b == 0) { m_conv(m, q + ".i_downsample.0", planes[li] * 4, cin, 1, 1); m_bn(m, q + ".i_downsample.1", planes[li] * 4); }
+            cin = planes[li] * 4;
+        }
+    // denoiser
+    const std::string d = "denoiser";
+    m_lin(m, d + ".time_mlp.1", 1024, 128); m_lin(m, d + ".time_mlp.3", 512, 512);
+    m_conv(m, d + ".intro", 128, 4, 3, 3); m_conv(m, d + ".ending", 4, 128, 3, 3);
+    int c = WIDTH;
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < enc[i]; ++j) m_naf(m, d + ".encoders." + std::to_string(i) + "." + std::to_string(j), c, true); c *= 2; }
+    c = WIDTH * 16;
+    for (int i = 0; i < 4; ++i) { c /= 2; for (int j = 0; j < 2; ++j) m_naf(m, d + ".decoders." + std::to_string(i) + "." + std::to_string(j), c, true); }
+    c = WIDTH * 16;
+    for (int j = 0; j < 8; ++j) m_naf(m, d + ".middle_blks." + std::to_string(j), c, true);
+    for (int i = 0; i < 4; ++i) { m_conv(m, d + ".ups." + std::to_string(i) + ".0", c * 2, c, 1, 1, false); c /= 2; }
+    c = WIDTH;
+    for (int i = 0; i < 4; ++i) { m_conv(m, d + ".downs." + std::to_string(i), 2 * c, c, 2, 2); c *= 2; }
+    c = WIDTH * 16;
+    for (int i = 0; i < 5; ++i) {
+        std::string p = d + ".hcas." + std::to_string(i);
+        m_lin(m, p + ".channel_mlp.0", c, c); m_lin(m, p + ".channel_mlp.2", c, c);
+        m_conv(m, p + ".spatial_mlp.0", c / 2, c, 1, 1); m_bn(m, p + ".spatial_mlp.1", c / 2);
+        m_conv(m, p + ".spatial_mlp.3", 1, c / 2, 1, 1); m_bn(m, p + ".spatial_mlp.4", 1);
+        m_conv(m, p + ".fused_mlp.0", c, c, 3, 3); m_bn(m, p + ".fused_mlp.1", c);
+        c /= 2;
+    }
+    const int s = L / 16;
+    m_conv(m, d + ".idc_conv", 2048 * s * s, 2048, 1, 1);
+    // fpg
+    const std::string f = "fpg";
+    m_conv(m, f + ".intro", 128, 4, 3, 3);
+    c = WIDTH;
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < enc[i]; ++j) m_naf(m, f + ".encoders." + std::to_string(i) + "." + std::to_string(j), c, false); c *= 2; }
+    c = WIDTH;
+    for (int i = 0; i < 4; ++i) { m_conv(m, f + ".downs." + std::to_string(i), 2 * c, c, 2, 2); c *= 2; }
+    m_conv(m, f + ".convs.0.0", c, c, 1, 1, false);
+    for (int i = 1; i < 5; ++i) { m_conv(m, f + ".convs." + std::to_string(i) + ".0", c * 2, c, 1, 1, false); c /= 2; }
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------ packing
+int upload_vec(hd_ctx* c, const std::vector<float>& v, const float** out) {
+    float* d = nullptr;
+    int rc = dev_alloc(c, &d, v.size());
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = d;
+    return HD_OK;
+}
+
+// BatchNorm(eval) as y = x*s + o, from host mirrors
+int bn_affine(hd_ctx* c, const std::string& bn, std::vector<float>& s, std::vector<float>& o) {
+    const RawTensor *w = find_raw(c, bn + ".weight"), *b = find_raw(c, bn + ".bias"), *m = find_raw(c, bn + ".running_mean"),
+                    *v = find_raw(c, bn + ".running_var");
+    if (!w || !b || !m || !v) HD_FAIL(c, HD_ERR_WEIGHTS, "missing BatchNorm tensors for %s", bn.c_str());
+    const size_t n = w->numel;
+    s.resize(n); o.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        s[i] = w->host[i] / std::sqrt(v->host[i] + 1e-5f);
+        o[i] = b->host[i] - m->host[i] * s[i];
+    }
+    return HD_OK;
+}
+
+struct PackOpts { int cin_pad = 0; bool centre_only = false; int S2 = 1; std::string bn; };
+
+// conv/linear weight `name`.weight (+ .bias) -> PackedW (bias folded with BN when opts.bn is set)
+int pack_weight(hd_ctx* c, const std::string& name, PackedW* out, const PackOpts& o = PackOpts()) {
+    const RawTensor* w = find_raw(c, name + ".weight");
+    if (!w) HD_FAIL(c, HD_ERR_WEIGHTS, "missing %s.weight", name.c_str());
+    const int N = (int)w->shape[0], Cin = (int)w->shape[1];
+    const int KH = w->shape.size() == 4 ? (int)w->shape[2] : 1, KW = w->shape.size() == 4 ? (int)w->shape[3] : 1;
+    const int cin_pad = o.cin_pad ? o.cin_pad : Cin;
+    const int ntaps = o.centre_only ? 1 : KH * KW;
+    PackP p{};
+    p.src = w->dev; p.N = N; p.Cin = Cin; p.Cin_pad = cin_pad; p.KH = KH; p.KW = KW; p.ntaps = ntaps;
+    p.centre_only = o.centre_only ? 1 : 0; p.S2 = o.S2;
+    const int K = ntaps * cin_pad;
+    p.Kp = (K + 63) / 64 * 64;
+    p.nt_total = (N + 31) / 32;
+    std::vector<float> s, off;
+    const float* nscale = nullptr;
+    if (!o.bn.empty()) {
+        int rc = bn_affine(c, o.bn, s, off);
+        if (rc) return rc;
+        rc = upload_vec(c, s, &nscale);
+        if (rc) return rc;
+    }
+    p.nscale = nscale;
+    const size_t n16 = (size_t)p.nt_total * (p.Kp / 16) * 64;
+    int rc = dev_alloc(c, &p.dst, n16);
+    if (rc) return rc;
+    const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 65535);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, 0, p);
+    HIPCHECK(c, hipGetLastError());
+    out->w = p.dst; out->N = N; out->K = K; out->Kp = p.Kp; out->nt_total = p.nt_total;
+    // bias (optionally folded with BN and/or permuted like the output channels)
+    const RawTensor* b = find_raw(c, name + ".bias");
+    out->bias = b ? b->dev : nullptr;
+    if (!o.bn.empty() || (o.S2 > 1 && b)) {
+        std::vector<float> bf(N, 0.f);
+        for (int n = 0; n < N; ++n) {
+            float v = b ? b->host[n] : 0.f;
+            if (!o.bn.empty()) v = v * s[n] + off[n];
+            bf[n] = v;
+        }
+        if (o.S2 > 1) {
+            std::vector<float> bp(N);
+            const int cg = N / o.S2;
+            for (int np = 0; np < N; ++np) bp[np] = bf[(np % cg) * o.S2 + np / cg];
+            bf.swap(bp);
+        }
+        rc = upload_vec(c, bf, &out->bias);
+        if (rc) return rc;
+    }
+    return HD_OK;
+}
+
+// ------------------------------------------------------------------------------------ GEMM dispatch
+template <class LD, class EP, bool PAIR>
+hipError_t launch_tile(const GemmP& p, bool t128, hipStream_t s) {
+    if constexpr (PAIR) return t128 ? launch_gemm<T128P, LD, EP>(p, s) : launch_gemm<T64P, LD, EP>(p, s);
+    else return t128 ? launch_gemm<T128, LD, EP>(p, s) : launch_gemm<T64, LD, EP>(p, s);
+}
+
+hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, bool t128, hipStream_t s) {
+    if (lk == LK_LN && ek == EK_BIASF32) return launch_tile<LdF32LN, EpBiasF32, false>(p, t128, s);
+    if (lk == LK_LN && ek == EK_GATE) return launch_tile<LdF32LN, EpGateBF16, true>(p, t128, s);
+    if (lk == LK_F32 && ek == EK_BIASF32) return launch_tile<LdF32Plain, EpBiasF32, false>(p, t128, s);
+    if (lk == LK_F32 && ek == EK_PIXSHUF) return launch_tile<LdF32Plain, EpPixShufF32, false>(p, t128, s);
+    if (lk == LK_BF16S && ek == EK_RESID) return launch_tile<LdBF16Scale, EpResidF32, false>(p, t128, s);
+    if (lk == LK_BF16 && ek == EK_RESID) return launch_tile<LdBF16Plain, EpResidF32, false>(p, t128, s);
+    if (lk == LK_BF16 && ek == EK_BIASBF16) return launch_tile<LdBF16Plain, EpBiasBF16, false>(p, t128, s);
+    if (lk == LK_CONV_F32 && ek == EK_BIASF32) return launch_tile<LdConv<false, false>, EpBiasF32, false>(p, t128, s);
+    if (lk == LK_CONV_F32G && ek == EK_BIASF32) return launch_tile<LdConv<false, true>, EpBiasF32, false>(p, t128, s);
+    if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, t128, s);
+    return hipErrorInvalidValue;
+}
+
+// Tile + split-K choice: fill >= 256 workgroups (256 CUs), keep >= 2 K-chunks per slice.
+void choose_tiling(hd_ctx* c, GemmP& p, bool pair, bool* t128) {
+    const int ncols = pair ? p.N / 2 : p.N;
+    const int nb = (ncols + 63) / 64;
+    const int mb128 = (p.M + 127) / 128, mb64 = (p.M + 63) / 64;
+    *t128 = (mb128 * nb >= 256);
+    const int wgs = (*t128 ? mb128 : mb64) * nb;
+    const int chunks = p.Kp / 64;
+    int ks = 1;
+    if (!*t128) {
+        for (int cand = 2; cand <= chunks; ++cand) {
+            if (chunks % cand) continue;
+            if (chunks / cand < 2) break;
+            if (wgs * cand > 512) break;
+            ks = cand;
+            if (wgs * cand >= 256) break;
+        }
+    }
+    const size_t per = (size_t)(pair ? 2 : 1) * 64 * 64 * sizeof(float);
+    if ((size_t)wgs * ks * per > c->slab_bytes || wgs > 8192) ks = 1;
+    p.ksplit = ks;
+    p.slab = c->slab;
+    p.counters = c->counters;
+}
+
+GemmP base_gemm(const PackedW& w, int M) {
+    GemmP p{};
+    p.M = M; p.N = w.N; p.K = w.K; p.Kp = w.Kp; p.nt_total = w.nt_total; p.W = w.w; p.bias = w.bias;
+    p.ksplit = 1; p.a_scale = 1.f; p.hw = 1; p.ln_eps = 1e-6f; p.shuffle_r = 1;
+    return p;
+}
+
+void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p, LdKind lk, EpKind ek) {
+    bool t128 = false;
+    choose_tiling(c, p, ek == EK_GATE, &t128);
+    const bool film = (lk == LK_LN);
+    size_t out_rows = (size_t)p.M * (ek == EK_PIXSHUF ? p.shuffle_r * p.shuffle_r : 1);
+    Op op;
+    op.name = name; op.out = p.out; op.out_elems = out_rows * p.ldo; op.out_bf16 = (ek == EK_GATE || ek == EK_BIASBF16) ? 1 : 0;
+    op.run = [c, p, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
+                        if (film && p.film == nullptr) {          // denoiser FiLM rows live in the (re-allocatable) table
+                            GemmP q = p;
+                            q.film = c->film_table;
+                            q.film_face_stride = c->film_face_stride;
+                            q.film_step_stride = c->film_step_stride;
+                            q.step_ptr = &c->step_state->step;
+                            return dispatch_gemm(q, lk, ek, t128, s);
+                        }
+                        return dispatch_gemm(p, lk, ek, t128, s);
+                    };
+    prog.push_back(op);
+}
+
+// One (Conditional)NAFBlock on level buffers (conditional_naf.py:108-136 / naf.py:105-126), six launches.
+// static_film: FPG blocks use the LayerNorm affine itself as the "FiLM" row (scale = shift = 0).
+void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Level& lv, const float* static_film) {
+    const int C = bw.C, M = lv.M, HW = lv.H * lv.H;
+    auto film_fields = [&](GemmP& p, int half) {
+        p.hw = HW;
+        p.film = static_film;                           // nullptr -> patched from the table at launch
+        p.film_bias_off = bw.film_off + (2 * half) * C;
+        p.film_gain_off = bw.film_off + (2 * half + 1) * C;
+        p.film_face_stride = 0; p.film_step_stride = 0; p.step_ptr = nullptr;
+    };
+    {   // LN1 + FiLM -> conv1 (+bias) -> T1
+        GemmP p = base_gemm(bw.conv1, M);
+        p.A = lv.X; p.lda = C; film_fields(p, 0);
+        p.out = lv.T1; p.ldo = 2 * C;
+        add_gemm(c, prog, bw.name + ".conv1", p, LK_LN, EK_BIASF32);
+    }
+    {   // depthwise 3x3 -> SimpleGate -> G, pooled mean
+        const float *T1 = lv.T1, *w = bw.dw_w, *b = bw.dw_b;
+        unsigned short* G = lv.G; float* pooled = lv.pooled;
+        const int H = lv.H, faces = M / HW;
+        prog.push_back({bw.name + ".conv2_gate_pool", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(dwconv_gate_pool_kernel, dim3(C / 32, faces), dim3(256), 0, s, T1, w, b, G, pooled, H, H, C);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = G; prog.back().out_elems = (size_t)M * C; prog.back().out_bf16 = 1;
+    }
+    {   // SCA 1x1 conv on the pooled vector
+        GemmP p = base_gemm(bw.sca, M / HW);
+        p.A = lv.pooled; p.lda = C; p.out = lv.S; p.ldo = C;
+        add_gemm(c, prog, bw.name + ".sca", p, LK_F32, EK_BIASF32);
+    }
+    {   // (G * S) -> conv3 -> y = x + beta * (.)
+        GemmP p = base_gemm(bw.conv3, M);
+        p.A = lv.G; p.lda = C; p.hw = HW; p.rowscale = lv.S;
+        p.out = lv.Y; p.ldo = C; p.resid = lv.X; p.ldr = C; p.rscale = bw.beta;
+        add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16S, EK_RESID);
+    }
+    {   // LN2 + FiLM -> conv4 -> SimpleGate -> G2 (bf16, reuses G)
+        GemmP p = base_gemm(bw.conv4, M);
+        p.A = lv.Y; p.lda = C; film_fields(p, 1);
+        p.out = lv.G; p.ldo = C;
+        add_gemm(c, prog, bw.name + ".conv4", p, LK_LN, EK_GATE);
+    }
+    {   // conv5 -> x' = y + gamma * (.)
+        GemmP p = base_gemm(bw.conv5, M);
+        p.A = lv.G; p.lda = C;
+        p.out = lv.X; p.ldo = C; p.resid = lv.Y; p.ldr = C; p.rscale = bw.gamma;
+        add_gemm(c, prog, bw.name + ".conv5", p, LK_BF16, EK_RESID);
+    }
+}
+
+void add_down(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const Level& src, const Level& dst) {
+    GemmP p = base_gemm(w, dst.M);                      // Conv2d(C, 2C, 2, 2) as a patch-gather GEMM
+    p.A = src.X; p.lda = src.C; p.Hin = src.H; p.Win = src.H; p.Cin = src.C; p.KH = 2; p.KW = 2; p.stride = 2; p.pad = 0;
+    p.Hout = dst.H; p.Wout = dst.H; p.ntaps = 4;
+    p.out = dst.X; p.ldo = dst.C;
+    add_gemm(c, prog, name, p, LK_CONV_F32, EK_BIASF32);
+}
+
+// 1x1 conv (no bias) + PixelShuffle(r) + skip add, written in place over the skip buffer
+void add_up(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const float* in, int M_in, int H_in,
+            int C_in, float* out, const float* skip, int r) {
+    GemmP p = base_gemm(w, M_in);
+    p.A = in; p.lda = C_in; p.Hin = H_in; p.Win = H_in; p.shuffle_r = r;
+    p.out = out; p.ldo = w.N / (r * r); p.resid = skip; p.bias = nullptr;
+    add_gemm(c, prog, name, p, LK_F32, EK_PIXSHUF);
+}
+
+void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const HcaW& hw, int idx, const float* in, const float* add,
+             float* out, int M, int H) {
+    GemmP p = base_gemm(hw.fused, M);
+    p.A = in; p.lda = hw.C; p.Hin = H; p.Win = H; p.Cin = hw.C; p.Hout = H; p.Wout = H; p.stride = 1;
+    if (hw.centre_only) { p.KH = 1; p.KW = 1; p.pad = 0; p.ntaps = 1; }
+    else { p.KH = 3; p.KW = 3; p.pad = 1; p.ntaps = 9; }
+    p.gate_c = c->gate_c[idx]; p.gate_s = c->gate_s[idx]; p.add_src = add;
+    p.out = out; p.ldo = hw.C; p.act = 1;
+    add_gemm(c, prog, name, p, LK_CONV_F32G, EK_BIASF32);
+}
+
+int run_ops(hd_ctx* c, std::vector<Op>& prog, hipStream_t s, int limit = -1) {
+    int n = 0;
+    for (auto& op : prog) {
+        if (limit >= 0 && n >= limit) break;
+        hipError_t e = op.run(s);
+        if (e != hipSuccess) HD_FAIL(c, HD_ERR_HIP, "launch of %s failed: %s", op.name.c_str(), hipGetErrorString(e));
+        ++n;
+    }
+    return HD_OK;
+}
+
+// --------------------------------------------------------------------------------------- workspace
+int alloc_workspace(hd_ctx* c, int B) {
+    if (B == c->B) return HD_OK;
+    if (c->B != 0) HD_FAIL(c, HD_ERR_INVALID, "batch size change (%d -> %d) needs a new context", c->B, B);
+    const int L = c->L;
+    int rc = 0;
+    for (int l = 0; l < 5; ++l) {
+        Level& v = c->lv[l];
+        v.C = WIDTH << l; v.H = L >> l; v.M = B * v.H * v.H;
+        const size_t mc = (size_t)v.M * v.C;
+        rc |= dev_alloc(c, &v.X, mc); rc |= dev_alloc(c, &v.Y, mc); rc |= dev_alloc(c, &v.T1, 2 * mc);
+        rc |= dev_alloc(c, &v.G, mc); rc |= dev_alloc(c, &v.pooled, (size_t)B * v.C); rc |= dev_alloc(c, &v.S, (size_t)B * v.C);
+        const int pi = 4 - l;                            // prior index: coarsest first
+        rc |= dev_alloc(c, &c->prior[pi], mc); rc |= dev_alloc(c, &c->gate_c[pi], (size_t)B * v.C);
+        rc |= dev_alloc(c, &c->gate_s[pi], (size_t)v.M);
+        if (rc) return rc;
+        const std::string s = std::to_string(l);
+        c->dbg["X" + s] = {v.X, {mc, 0}}; c->dbg["Y" + s] = {v.Y, {mc, 0}}; c->dbg["T1_" + s] = {v.T1, {2 * mc, 0}};
+        c->dbg["G" + s] = {v.G, {mc, 1}}; c->dbg["pooled" + s] = {v.pooled, {(size_t)B * v.C, 0}}; c->dbg["S" + s] = {v.S, {(size_t)B * v.C, 0}};
+        const std::string ps = std::to_string(pi);
+        c->dbg["prior" + ps] = {c->prior[pi], {mc, 0}}; c->dbg["wc" + ps] = {c->gate_c[pi], {(size_t)B * v.C, 0}};
+        c->dbg["ws" + ps] = {c->gate_s[pi], {(size_t)v.M, 0}};
+    }
+    const size_t nlat = (size_t)B * 4 * L * L;
+    rc |= dev_alloc(c, &c->lat, nlat); rc |= dev_alloc(c, &c->eps, nlat);
+    rc |= dev_alloc(c, &c->idc_term, (size_t)B * 2048 * c->S * c->S); rc |= dev_alloc(c, &c->id_emb, (size_t)B * 2048);
+    rc |= dev_alloc(c, &c->pool_tmp, (size_t)B * 2048); rc |= dev_alloc(c, &c->mlp_tmp, (size_t)B * 2048);
+    rc |= dev_alloc(c, &c->sp_tmp, (size_t)c->lv[0].M * 1024);      // max over levels of M_l * C_l/2 = B*L*L*64... generous
+    if (rc) return rc;
+    c->dbg["lat"] = {c->lat, {nlat, 0}}; c->dbg["eps"] = {c->eps, {nlat, 0}};
+    c->dbg["idc"] = {c->idc_term, {(size_t)B * 2048 * c->S * c->S, 0}}; c->dbg["id_emb"] = {c->id_emb, {(size_t)B * 2048, 0}};
+    // ResNet activations (channels-last bf16); largest is conv1 output B x 64x64 x 64 == layer1 B x 32x32 x 256
+    const size_t rmax = (size_t)B * 64 * 64 * 64;
+    for (int i = 0; i < 4; ++i) rc |= dev_alloc(c, &c->res_buf[i], rmax);
+    rc |= dev_alloc(c, &c->face8, (size_t)B * 128 * 128);
+    if (rc) return rc;
+    c->B = B;
+    return HD_OK;
+}
+
+// ----------------------------------------------------------------------------- program construction
+int build_denoiser_program(hd_ctx* c) {
+    std::vector<Op>& prog = c->program;
+    prog.clear();
+    const int B = c->B, L = c->L;
+    const RawTensor *iw = find_raw(c, "denoiser.intro.weight"), *ib = find_raw(c, "denoiser.intro.bias");
+    const RawTensor *ew = find_raw(c, "denoiser.ending.weight"), *eb = find_raw(c, "denoiser.ending.bias");
+    {
+        const float *lat = c->lat, *w = iw->dev, *b = ib->dev; float* out = c->lv[0].X;
+        const int M = c->lv[0].M;
+        prog.push_back({"intro", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, lat, w, b, out, B, L, c->step_state, c->advance);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
+    }
+    const int enc[4] = {2, 2, 4, 8};
+    int bi = 0;
+    for (int l = 0; l < 4; ++l) {
+        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->lv[l], nullptr);
+        add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->lv[l], c->lv[l + 1]);
+    }
+    for (int j = 0; j < 8; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->lv[4], nullptr);
+    // x + idc_conv(id) -> HCA0 (model.py:245-247); the add is folded into the HCA loader
+    add_hca(c, prog, "hcas.0", c->hca[0], 0, c->lv[4].X, c->idc_term, c->lv[4].Y, c->lv[4].M, c->lv[4].H);
+    for (int i = 0; i < 4; ++i) {
+        const int l = 3 - i;
+        const Level &hi = c->lv[l + 1], &lo = c->lv[l];
+        add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], hi.Y, hi.M, hi.H, hi.C, lo.X, lo.X, 2);
+        for (int j = 0; j < 2; ++j) add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr);
+        add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], i + 1, lo.X, nullptr, lo.Y, lo.M, lo.H);
+    }
+    {
+        const float *X = c->lv[0].Y, *w = ew->dev, *b = eb->dev; float* eps = c->eps;
+        const int M = c->lv[0].M;
+        prog.push_back({"ending", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(ending_conv_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, w, b, eps, B, L);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = eps; prog.back().out_elems = (size_t)B * 4 * L * L;
+    }
+    return HD_OK;
+}
+
+// HCA gates from prior maps (hca.py:33-48): w_c -> gate_c[i], w_s -> gate_s[i]
+void add_gates(hd_ctx* c, std::vector<Op>& prog, int i) {
+    const Level& lv = c->lv[4 - i];
+    const HcaW& hw = c->hca[i];
+    const int C = hw.C, HW = lv.H * lv.H, B = c->B, M = lv.M;
+    const float* prior = c->prior[i];
+    float *pool = c->pool_tmp, *mlp = c->mlp_tmp, *sp = c->sp_tmp, *gc = c->gate_c[i], *gs = c->gate_s[i];
+    const std::string n = "hcas." + std::to_string(i);
+    prog.push_back({n + ".pool", [=](hipStream_t s) -> hipError_t {
+                        hipLaunchKernelGGL(pool_avgmax_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, prior, pool, HW, C);
+                        return hipGetLastError();
+                    }});
+    prog.back().out = pool; prog.back().out_elems = (size_t)B * C;
+    { GemmP p = base_gemm(hw.mlp0, B); p.A = pool; p.lda = C; p.out = mlp; p.ldo = C; p.act = 1; add_gemm(c, prog, n + ".channel_mlp.0", p, LK_F32, EK_BIASF32); }
+    { GemmP p = base_gemm(hw.mlp2, B); p.A = mlp; p.lda = C; p.out = gc; p.ldo = C; p.act = 2; add_gemm(c, prog, n + ".channel_mlp.2", p, LK_F32, EK_BIASF32); }
+    { GemmP p = base_gemm(hw.sp0, M); p.A = prior; p.lda = C; p.out = sp; p.ldo = C / 2; p.act = 1; add_gemm(c, prog, n + ".spatial_mlp.0", p, LK_F32, EK_BIASF32); }
+    {
+        const float* w3 = hw.sp3_w; const float b3 = hw.sp3_b;
+        prog.push_back({n + ".spatial_mlp.3", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(rowdot_sigmoid_kernel, dim3((M + 3) / 4), dim3(256), 0, s, sp, w3, b3, gs, M, C / 2);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = gs; prog.back().out_elems = (size_t)M;
+    }
+}
+
+void add_idc_term(hd_ctx* c, std::vector<Op>& prog) {
+    GemmP p = base_gemm(c->idc_conv, c->B);
+    p.A = c->id_emb; p.lda = 2048; p.out = c->idc_term; p.ldo = c->idc_conv.N;
+    add_gemm(c, prog, "idc_conv", p, LK_F32, EK_BIASF32);
+}
+
+void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
+    const int B = c->B, L = c->L;
+    const RawTensor *iw = find_raw(c, "fpg.intro.weight"), *ib = find_raw(c, "fpg.intro.bias");
+    {
+        const float *w = iw->dev, *b = ib->dev; float* out = c->lv[0].X; const int M = c->lv[0].M;
+        prog.push_back({"fpg.intro", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, cr_latent_dev, w, b, out, B, L, c->step_state, 0);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
+    }
+    const int enc[4] = {2, 2, 4, 8};
+    int bi = 0;
+    for (int l = 0; l < 4; ++l) {
+        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->fpg_blocks[bi++], c->lv[l], c->fpg_ln_pack);
+        add_down(c, prog, "fpg.downs." + std::to_string(l), c->fpg_down[l], c->lv[l], c->lv[l + 1]);
+    }
+    // convs[0]: 1x1, PixelShuffle(1) == identity -> prior0; then 4x (1x1, PixelShuffle(2), + enc skip)
+    add_up(c, prog, "fpg.convs.0", c->fpg_convs[0], c->lv[4].X, c->lv[4].M, c->lv[4].H, c->lv[4].C, c->prior[0], nullptr, 1);
+    for (int i = 1; i < 5; ++i) {
+        const Level &hi = c->lv[5 - i], &lo = c->lv[4 - i];
+        // out = shuffled + skip: write into prior[i] with the encoder output as the additive source
+        GemmP p = base_gemm(c->fpg_convs[i], hi.M);
+        p.A = c->prior[i - 1]; p.lda = hi.C; p.Hin = hi.H; p.Win = hi.H; p.shuffle_r = 2;
+        p.out = c->prior[i]; p.ldo = lo.C; p.resid = lo.X; p.bias = nullptr;
+        add_gemm(c, prog, "fpg.convs." + std::to_string(i), p, LK_F32, EK_PIXSHUF);
+    }
+}
+
+void add_resconv(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const ResConv& rc, const unsigned short* in, int Hin,
+                 unsigned short* out, const unsigned short* resid, bool relu) {
+    const int Hout = (Hin + 2 * rc.pad - rc.k) / rc.stride + 1;
+    GemmP p = base_gemm(rc.w, c->B * Hout * Hout);
+    p.A = in; p.out = out; p.ldo = rc.cout; p.resid = resid; p.ldr = rc.cout; p.act = relu ? 1 : 0;
+    if (rc.k == 1 && rc.stride == 1) {
+        p.lda = rc.cin;
+        add_gemm(c, prog, name, p, LK_BF16, EK_BIASBF16);
+    } else {
+        const int cin = rc.w.K / (rc.k * rc.k);          // padded Cin
+        p.lda = cin; p.Hin = Hin; p.Win = Hin; p.Cin = cin; p.KH = rc.k; p.KW = rc.k; p.stride = rc.stride; p.pad = rc.pad;
+        p.Hout = Hout; p.Wout = Hout; p.ntaps = rc.k * rc.k;
+        add_gemm(c, prog, name, p, LK_CONV_BF16, EK_BIASBF16);
+    }
+}
+
+// ResNet-50 trunk (idc/model.py:122-135) on cr_face -> id_emb [B][2048]
+void add_resnet(hd_ctx* c, std::vector<Op>& prog, const float* cr_face_dev) {
+    const int B = c->B;
+    {
+        uint4* f8 = c->face8; const size_t npix = (size_t)B * 128 * 128;
+        prog.push_back({"idc.input", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, cr_face_dev, f8, 128 * 128, npix);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = f8; prog.back().out_elems = npix * 8; prog.back().out_bf16 = 1;
+    }
+    unsigned short *b0 = c->res_buf[0], *b1 = c->res_buf[1], *b2 = c->res_buf[2], *b3 = c->res_buf[3];
+    add_resconv(c, prog, "idc.conv1", c->res_conv1, reinterpret_cast<const unsigned short*>(c->face8), 128, b0, nullptr, true);
+    {
+        const size_t total = (size_t)B * 32 * 32 * 64;
+        prog.push_back({"idc.max_pool", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(maxpool3x3s2_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b0, b1, B, 64, 64, 64);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = b1; prog.back().out_elems = total; prog.back().out_bf16 = 1;
+    }
+    unsigned short *x = b1, *y1 = b0, *y2 = b2, *idn = b3;
+    int H = 32, bi = 0;
+    const int res_layers[4] = {3, 4, 6, 3};
+    for (int li = 0; li < 4; ++li)
+        for (int b = 0; b < res_layers[li]; ++b) {
+            const ResBlock& rb = c->res_blocks[bi++];
+            const std::string q = "idc.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int Hout = H / rb.c2.stride;
+            add_resconv(c, prog, q + ".conv1", rb.c1, x, H, y1, nullptr, true);
+            add_resconv(c, prog, q + ".conv2", rb.c2, y1, H, y2, nullptr, true);
+            const unsigned short* identity = x;
+            if (rb.has_ds) { add_resconv(c, prog, q + ".i_downsample", rb.ds, x, H, idn, nullptr, false); identity = idn; }
+            // conv3 + BN + identity -> ReLU, written to y1 (free again), then rotate
+            add_resconv(c, prog, q + ".conv3", rb.c3, y2, Hout, y1, identity, true);
+            std::swap(x, y1);
+            H = Hout;
+        }
+    {
+        float* emb = c->id_emb; const unsigned short* xin = x; const int HW = H * H;
+        prog.push_back({"idc.avgpool", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(avgpool_bf16_kernel, dim3(2048 / 256, B), dim3(256), 0, s, xin, emb, HW, 2048);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = emb; prog.back().out_elems = (size_t)B * 2048;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ FiLM
+int ensure_film_rows(hd_ctx* c, int rows) {
+    if (rows <= c->film_rows_cap) return HD_OK;
+    dev_free(c, c->t_dev); dev_free(c, c->temb_a); dev_free(c, c->temb_b); dev_free(c, c->temb_c); dev_free(c, c->film_table);
+    int rc = 0;
+    rc |= dev_alloc(c, &c->t_dev, rows); rc |= dev_alloc(c, &c->temb_a, (size_t)rows * 128);
+    rc |= dev_alloc(c, &c->temb_b, (size_t)rows * 1024); rc |= dev_alloc(c, &c->temb_c, (size_t)rows * 512);
+    rc |= dev_alloc(c, &c->film_table, (size_t)rows * c->film_total);
+    if (rc) return rc;
+    c->film_rows_cap = rows;
+    c->dbg["film"] = {c->film_table, {(size_t)rows * c->film_total, 0}};
+    c->dbg["temb"] = {c->temb_c, {(size_t)rows * 512, 0}};
+    return HD_OK;
+}
+
+// t (device, n values) -> FiLM table rows [n][film_total] (gain/bias with LN affine folded)
+int compute_film(hd_ctx* c, const float* t_dev, int n, hipStream_t s) {
+    const RawTensor *w1 = find_raw(c, "denoiser.time_mlp.1.weight"), *b1 = find_raw(c, "denoiser.time_mlp.1.bias");
+    const RawTensor *w3 = find_raw(c, "denoiser.time_mlp.3.weight"), *b3 = find_raw(c, "denoiser.time_mlp.3.bias");
+    hipLaunchKernelGGL(time_embed_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, s, t_dev, c->freq_dev, c->temb_a, n);
+    hipLaunchKernelGGL((linear_f32_kernel<false>), dim3(1024 / 64, (n + 63) / 64), dim3(256), 0, s, c->temb_a, 128, w1->dev, b1->dev, c->temb_b, 1024, n, 1024, 128);
+    hipLaunchKernelGGL((linear_f32_kernel<true>), dim3(512 / 64, (n + 63) / 64), dim3(256), 0, s, c->temb_b, 1024, w3->dev, b3->dev, c->temb_c, 512, n, 512, 512);
+    hipLaunchKernelGGL((linear_f32_kernel<true>), dim3((c->film_total + 63) / 64, (n + 63) / 64), dim3(256), 0, s, c->temb_c, 512, c->film_W, c->film_b,
+                       c->film_table, c->film_total, n, c->film_total, FILM_IN);
+    hipLaunchKernelGGL(film_fold_kernel, dim3(2048 / 256, (unsigned)c->den_blocks.size(), n), dim3(256), 0, s, c->film_table, c->ln_pack, c->film_blocks_dev, c->film_total);
+    HIPCHECK(c, hipGetLastError());
+    return HD_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+extern "C" {
+
+const char* hd_last_error(const hd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hd_create(hd_ctx** out, int latent_res, int device) {
+    if (!out) return HD_ERR_INVALID;
+    *out = nullptr;
+    if (latent_res < 16 || latent_res % 16 != 0 || latent_res > 64) { g_create_error = "latent_res must be 16, 32, 48 or 64"; return HD_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available"; return HD_ERR_HIP; }
+    if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return HD_ERR_INVALID; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return HD_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return HD_ERR_HIP; }
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_create_error = std::string("this library is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName;
+        return HD_ERR_INVALID;
+    }
+    hd_ctx* c = new hd_ctx();
+    c->L = latent_res; c->device = device; c->S = latent_res / 16;
+    c->slab_bytes = (size_t)64 << 20;
+    int rc = dev_alloc(c, &c->slab, c->slab_bytes / sizeof(float));
+    if (!rc) rc = dev_alloc(c, &c->counters, 8192);
+    if (!rc) rc = dev_alloc(c, &c->step_state, 1);
+    if (!rc) rc = dev_alloc(c, &c->freq_dev, 64);
+    if (rc) { g_create_error = c->err; hd_destroy(c); return rc; }
+    (void)hipMemset(c->counters, 0, 8192 * sizeof(unsigned));
+    (void)hipMemset(c->step_state, 0, sizeof(StepState));
+    float freq[64];
+    const float e = (float)(-(std::log(10000.0) / 63.0));       // model.py:25: python double, then fp32 tensor math
+    for (int k = 0; k < 64; ++k) freq[k] = expf((float)k * e);
+    (void)hipMemcpy(c->freq_dev, freq, sizeof(freq), hipMemcpyHostToDevice);
+    (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
+    *out = c;
+    return HD_OK;
+}
+
+void hd_destroy(hd_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto& kv : c->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    for (void* p : c->allocs) if (p) (void)hipFree(p);
+    delete c;
+}
+
+int hd_load_weights(hd_ctx* c, const hd_tensor_desc* t, int n) {
+    if (!c || (!t && n > 0)) return HD_ERR_INVALID;
+    if (c->finalized) HD_FAIL(c, HD_ERR_INVALID, "weights already finalized");
+    HIPCHECK(c, hipSetDevice(c->device));
+    for (int i = 0; i < n; ++i) {
+        if (!t[i].name || t[i].ndim < 0 || t[i].ndim > 4) HD_FAIL(c, HD_ERR_INVALID, "bad tensor descriptor %d", i);
+        const std::string name = t[i].name;
+        RawTensor r;
+        r.numel = 1;
+        for (int d = 0; d < t[i].ndim; ++d) { r.shape.push_back(t[i].shape[d]); r.numel *= (size_t)t[i].shape[d]; }
+        const bool counter = name.size() > 19 && name.compare(name.size() - 19, 19, "num_batches_tracked") == 0;
+        if (!counter) {
+            if (!t[i].data) HD_FAIL(c, HD_ERR_INVALID, "tensor %s has no data", name.c_str());
+            HIPCHECK(c, hipMalloc(reinterpret_cast<void**>(&r.dev), r.numel * sizeof(float) + 256));
+            HIPCHECK(c, hipMemcpy(r.dev, t[i].data, r.numel * sizeof(float), t[i].is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+            if (r.numel <= HOST_MIRROR_MAX) {
+                r.host.resize(r.numel);
+                HIPCHECK(c, hipMemcpy(r.host.data(), t[i].data, r.numel * sizeof(float), t[i].is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+            }
+        }
+        auto it = c->raw.find(name);
+        if (it != c->raw.end() && it->second.dev) (void)hipFree(it->second.dev);
+        c->raw[name] = std::move(r);
+    }
+    return HD_OK;
+}
+
+int hd_finalize_weights(hd_ctx* c) {
+    if (!c) return HD_ERR_INVALID;
+    if (c->finalized) return HD_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    // ---- strict key / shape check ----
+    const auto man = build_manifest(c->L);
+    for (const auto& e : man) {
+        const RawTensor* r = find_raw(c, e.first);
+        if (!r) HD_FAIL(c, HD_ERR_WEIGHTS, "Missing key in state_dict: %s", e.first.c_str());
+        if (r->shape != e.second) HD_FAIL(c, HD_ERR_WEIGHTS, "size mismatch for %s", e.first.c_str());
+    }
+    if (c->raw.size() != man.size()) {
+        std::unordered_map<std::string, int> known;
+        for (const auto& e : man) known[e.first] = 1;
+        for (const auto& kv : c->raw)
+            if (!known.count(kv.first)) HD_FAIL(c, HD_ERR_WEIGHTS, "Unexpected key in state_dict: %s", kv.first.c_str());
+    }
+    int rc = 0;
+    // ---- NAF blocks (denoiser in execution order, then FPG) ----
+    auto load_block = [&](const std::string& p, int C, BlockW& bw) -> int {
+        bw.name = p; bw.C = C;
+        int r = 0;
+        r |= pack_weight(c, p + ".conv1", &bw.conv1); r |= pack_weight(c, p + ".conv3", &bw.conv3);
+        r |= pack_weight(c, p + ".sca.1", &bw.sca); r |= pack_weight(c, p + ".conv4", &bw.conv4);
+        r |= pack_weight(c, p + ".conv5", &bw.conv5);
+        if (r) return r;
+        bw.dw_w = find_raw(c, p + ".conv2.weight")->dev; bw.dw_b = find_raw(c, p + ".conv2.bias")->dev;
+        bw.beta = find_raw(c, p + ".beta")->dev; bw.gamma = find_raw(c, p + ".gamma")->dev;
+        c->weight_bytes_per_step += 0;   // accounted below for denoiser blocks only
+        return HD_OK;
+    };
+    const int enc[4] = {2, 2, 4, 8};
+    std::vector<std::pair<std::string, int>> order;
+    for (int l = 0; l < 4; ++l) for (int j = 0; j < enc[l]; ++j) order.push_back({"denoiser.encoders." + std::to_string(l) + "." + std::to_string(j), WIDTH << l});
+    for (int j = 0; j < 8; ++j) order.push_back({"denoiser.middle_blks." + std::to_string(j), WIDTH << 4});
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) order.push_back({"denoiser.decoders." + std::to_string(i) + "." + std::to_string(j), WIDTH << (3 - i)});
+    int off = 0;
+    for (auto& e : order) {
+        BlockW bw;
+        rc = load_block(e.first, e.second, bw);
+        if (rc) return rc;
+        bw.film_off = off;
+        off += 4 * e.second;
+        c->den_block_index[e.first] = (int)c->den_blocks.size();
+        c->den_blocks.push_back(bw);
+    }
+    c->film_total = off;
+    off = 0;
+    for (int l = 0; l < 4; ++l)
+        for (int j = 0; j < enc[l]; ++j) {
+            BlockW bw;
+            rc = load_block("fpg.encoders." + std::to_string(l) + "." + std::to_string(j), WIDTH << l, bw);
+            if (rc) return rc;
+            bw.film_off = off;
+            off += 4 * (WIDTH << l);
+            c->fpg_blocks.push_back(bw);
+        }
+    const int fpg_film_total = off;
+    // ---- FiLM: concatenated Linear(256,4C) weights/biases, LN affine in table layout ----
+    rc |= dev_alloc(c, &c->film_W, (size_t)c->film_total * FILM_IN); rc |= dev_alloc(c, &c->film_b, c->film_total);
+    rc |= dev_alloc(c, &c->ln_pack, c->film_total); rc |= dev_alloc(c, &c->fpg_ln_pack, fpg_film_total);
+    rc |= dev_alloc(c, &c->film_blocks_dev, c->den_blocks.size());
+    if (rc) return rc;
+    std::vector<FilmBlock> fbs;
+    auto copy_ln = [&](const BlockW& bw, float* dst) -> int {
+        const char* names[4] = {".norm1.bias", ".norm1.weight", ".norm2.bias", ".norm2.weight"};
+        for (int q = 0; q < 4; ++q)
+            HIPCHECK(c, hipMemcpy(dst + bw.film_off + q * bw.C, find_raw(c, bw.name + names[q])->dev, bw.C * sizeof(float), hipMemcpyDeviceToDevice));
+        return HD_OK;
+    };
+    for (const BlockW& bw : c->den_blocks) {
+        HIPCHECK(c, hipMemcpy(c->film_W + (size_t)bw.film_off * FILM_IN, find_raw(c, bw.name + ".mlp.1.weight")->dev, (size_t)4 * bw.C * FILM_IN * sizeof(float), hipMemcpyDeviceToDevice));
+        HIPCHECK(c, hipMemcpy(c->film_b + bw.film_off, find_raw(c, bw.name + ".mlp.1.bias")->dev, (size_t)4 * bw.C * sizeof(float), hipMemcpyDeviceToDevice));
+        rc = copy_ln(bw, c->ln_pack);
+        if (rc) return rc;
+        fbs.push_back({bw.film_off, bw.C});
+    }
+    for (const BlockW& bw : c->fpg_blocks) { rc = copy_ln(bw, c->fpg_ln_pack); if (rc) return rc; }
+    HIPCHECK(c, hipMemcpy(c->film_blocks_dev, fbs.data(), fbs.size() * sizeof(FilmBlock), hipMemcpyHostToDevice));
+    // ---- downs / ups / fpg convs / idc_conv ----
+    for (int i = 0; i < 4; ++i) {
+        rc |= pack_weight(c, "denoiser.downs." + std::to_string(i), &c->den_down[i]);
+        rc |= pack_weight(c, "denoiser.ups." + std::to_string(i) + ".0", &c->den_up[i]);
+        rc |= pack_weight(c, "fpg.downs." + std::to_string(i), &c->fpg_down[i]);
+    }
+    for (int i = 0; i < 5; ++i) rc |= pack_weight(c, "fpg.convs." + std::to_string(i) + ".0", &c->fpg_convs[i]);
+    { PackOpts o; o.S2 = c->S * c->S; rc |= pack_weight(c, "denoiser.idc_conv", &c->idc_conv, o); }
+    if (rc) return rc;
+    // ---- HCAs ----
+    for (int i = 0; i < 5; ++i) {
+        HcaW& h = c->hca[i];
+        const std::string p = "denoiser.hcas." + std::to_string(i);
+        h.C = (WIDTH << 4) >> i;
+        h.centre_only = ((c->L >> (4 - i)) == 1);         // 1x1 map: only the centre tap sees data
+        rc |= pack_weight(c, p + ".channel_mlp.0", &h.mlp0); rc |= pack_weight(c, p + ".channel_mlp.2", &h.mlp2);
+        { PackOpts o; o.bn = p + ".spatial_mlp.1"; rc |= pack_weight(c, p + ".spatial_mlp.0", &h.sp0, o); }
+        { PackOpts o; o.bn = p + ".fused_mlp.1"; o.centre_only = h.centre_only; rc |= pack_weight(c, p + ".fused_mlp.0", &h.fused, o); }
+        if (rc) return rc;
+        std::vector<float> s, o2;
+        rc = bn_affine(c, p + ".spatial_mlp.4", s, o2);
+        if (rc) return rc;
+        const RawTensor *w3 = find_raw(c, p + ".spatial_mlp.3.weight"), *b3 = find_raw(c, p + ".spatial_mlp.3.bias");
+        std::vector<float> wf(w3->numel);
+        for (size_t k = 0; k < w3->numel; ++k) wf[k] = w3->host[k] * s[0];
+        h.sp3_b = b3->host[0] * s[0] + o2[0];
+        rc = upload_vec(c, wf, &h.sp3_w);
+        if (rc) return rc;
+    }
+    // ---- ResNet-50 (conv + BN folded) ----
+    auto load_res = [&](const std::string& conv, const std::string& bn, int cin, int cout, int k, int stride, int pad, ResConv& r) -> int {
+        PackOpts o; o.bn = bn;
+        if (cin == 3) o.cin_pad = 8;
+        r.cin = cin; r.cout = cout; r.k = k; r.stride = stride; r.pad = pad;
+        return pack_weight(c, conv, &r.w, o);
+    };
+    rc = load_res("idc.conv1", "idc.batch_norm1", 3, 64, 7, 2, 3, c->res_conv1);
+    if (rc) return rc;
+    {
+        const int res_layers[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+        int cin = 64;
+        for (int li = 0; li < 4; ++li)
+            for (int b = 0; b < res_layers[li]; ++b) {
+                const std::string q = "idc.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+                const int stride = (b == 0 && li > 0) ? 2 : 1;
+                ResBlock rb;
+                rc |= load_res(q + ".conv1", q + ".batch_norm1", cin, planes[li], 1, 1, 0, rb.c1);
+                rc |= load_res(q + ".conv2", q + ".batch_norm2", planes[li], planes[li], 3, stride, 1, rb.c2);
+                rc |= load_res(q + ".conv3", q + ".batch_norm3", planes[li], planes[li] * 4, 1, 1, 0, rb.c3);
+                if (b == 0) { rb.has_ds = true; rc |= load_res(q + ".i_downsample.0", q + ".i_downsample.1", cin, planes[li] * 4, 1, stride, 0, rb.ds); }
+                if (rc) return rc;
+                c->res_blocks.push_back(rb);
+                cin = planes[li] * 4;
+            }
+    }
+    HIPCHECK(c, hipDeviceSynchronize());
+    // ---- algorithmic per-step figures of the step-variant denoiser (effective taps only) ----
+    int64_t params = 0;
+    double macs = 0.0;   // per face
+    auto add_w = [&](const PackedW& w, double rows_per_face) { params += (int64_t)w.N * w.K; macs += rows_per_face * (double)w.N * w.K; };
+    {
+        int bi = 0;
+        auto blocks_at = [&](int l, int n) {
+            const double hw = (double)(c->L >> l) * (c->L >> l);
+            for (int j = 0; j < n; ++j) {
+                const BlockW& b = c->den_blocks[bi++];
+                add_w(b.conv1, hw); add_w(b.conv3, hw); add_w(b.conv4, hw); add_w(b.conv5, hw); add_w(b.sca, 1.0);
+                params += 2 * b.C * 9 + 2 * b.C; macs += hw * 2 * b.C * 9;   // depthwise (nominal taps)
+            }
+        };
+        for (int l = 0; l < 4; ++l) blocks_at(l, enc[l]);
+        blocks_at(4, 8);
+        for (int i = 0; i < 4; ++i) blocks_at(3 - i, 2);
+        for (int l = 0; l < 4; ++l) {
+            const double hwd = (double)(c->L >> (l + 1)) * (c->L >> (l + 1));
+            add_w(c->den_down[l], hwd);
+            add_w(c->den_up[l], (double)(c->L >> (4 - l)) * (c->L >> (4 - l)));
+        }
+        for (int i = 0; i < 5; ++i) { const double hw = (double)(c->L >> (4 - i)) * (c->L >> (4 - i)); add_w(c->hca[i].fused, hw); }
+        params += 2 * 128 * 36; macs += 2.0 * c->L * c->L * 128 * 36;
+    }
+    c->weight_bytes_per_step = params * 2;
+    c->flops_per_face_step = 2.0 * macs;
+    c->finalized = true;
+    return HD_OK;
+}
+
+static int check_ready(hd_ctx* c, bool need_prepared) {
+    if (!c) return HD_ERR_INVALID;
+    if (!c->finalized) HD_FAIL(c, HD_ERR_NOT_READY, "weights are not loaded/finalized");
+    if (need_prepared && !c->prepared) HD_FAIL(c, HD_ERR_NOT_READY, "hd_prepare has not been called for this batch");
+    return HD_OK;
+}
+
+static int prepare_common(hd_ctx* c, int batch) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (batch <= 0 || batch > 4096) HD_FAIL(c, HD_ERR_INVALID, "batch must be in [1, 4096]");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const bool fresh = (c->B == 0);
+    rc = alloc_workspace(c, batch);
+    if (rc) return rc;
+    if (fresh) rc = build_denoiser_program(c);
+    return rc;
+}
+
+int hd_prepare(hd_ctx* c, int batch, const float* cr_latent, const float* cr_face, const float* id_emb, void* stream) {
+    int rc = prepare_common(c, batch);
+    if (rc) return rc;
+    if (!cr_latent || (!cr_face == !id_emb)) HD_FAIL(c, HD_ERR_INVALID, "need cr_latent and exactly one of cr_face / id_emb");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    std::vector<Op> prog;
+    add_fpg(c, prog, cr_latent);
+    if (cr_face) add_resnet(c, prog, cr_face);
+    else HIPCHECK(c, hipMemcpyAsync(c->id_emb, id_emb, (size_t)batch * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < 5; ++i) add_gates(c, prog, i);
+    add_idc_term(c, prog);
+    rc = run_ops(c, prog, s, c->prep_limit);
+    c->prep_program.swap(prog);
+    if (rc) return rc;
+    c->prepared = true;
+    return HD_OK;
+}
+
+int hd_prepare_from_priors(hd_ctx* c, int batch, const float* const priors[5], const float* id_emb, void* stream) {
+    int rc = prepare_common(c, batch);
+    if (rc) return rc;
+    if (!priors || !id_emb) HD_FAIL(c, HD_ERR_INVALID, "priors and id_emb are required");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int i = 0; i < 5; ++i) {
+        if (!priors[i]) HD_FAIL(c, HD_ERR_INVALID, "prior %d is NULL", i);
+        const Level& lv = c->lv[4 - i];
+        const size_t total = (size_t)lv.M * lv.C;
+        hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, priors[i], c->prior[i], lv.C, lv.H * lv.H, total);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(c->id_emb, id_emb, (size_t)batch * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    std::vector<Op> prog;
+    for (int i = 0; i < 5; ++i) add_gates(c, prog, i);
+    add_idc_term(c, prog);
+    rc = run_ops(c, prog, s);
+    if (rc) return rc;
+    c->prepared = true;
+    return HD_OK;
+}
+
+int hd_fpg(hd_ctx* c, int batch, const float* cr_latent, float* const priors_out[5], void* stream) {
+    int rc = prepare_common(c, batch);
+    if (rc) return rc;
+    if (!cr_latent || !priors_out) HD_FAIL(c, HD_ERR_INVALID, "hd_fpg: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    std::vector<Op> prog;
+    add_fpg(c, prog, cr_latent);
+    rc = run_ops(c, prog, s);
+    if (rc) return rc;
+    for (int i = 0; i < 5; ++i) {
+        if (!priors_out[i]) continue;
+        const Level& lv = c->lv[4 - i];
+        const size_t total = (size_t)lv.M * lv.C;
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->prior[i], priors_out[i], lv.C, lv.H * lv.H, total);
+    }
+    HIPCHECK(c, hipGetLastError());
+    return HD_OK;
+}
+
+int hd_idc(hd_ctx* c, int batch, const float* cr_face, float* id_emb_out, void* stream) {
+    int rc = prepare_common(c, batch);
+    if (rc) return rc;
+    if (!cr_face || !id_emb_out) HD_FAIL(c, HD_ERR_INVALID, "hd_idc: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    std::vector<Op> prog;
+    add_resnet(c, prog, cr_face);
+    rc = run_ops(c, prog, s);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpyAsync(id_emb_out, c->id_emb, (size_t)batch * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return HD_OK;
+}
+
+int hd_scheduler_step(float* x_inout, const float* eps, const float* coef7, const float* noise, uint64_t seed, int step,
+                      int64_t n_elems, void* stream) {
+    if (!x_inout || !eps || !coef7 || n_elems <= 0) return HD_ERR_INVALID;
+    Coef7 k;
+    for (int i = 0; i < 7; ++i) k.c[i] = coef7[i];
+    hipLaunchKernelGGL(sched_step_direct_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x_inout, eps, k, noise, (unsigned long long)seed, step, (long long)n_elems);
+    return hipGetLastError() == hipSuccess ? HD_OK : HD_ERR_HIP;
+}
+
+int hd_eps(hd_ctx* c, const float* x, const float* timesteps, int n_t, float* eps_out, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!x || !timesteps || !eps_out || (n_t != 1 && n_t != c->B)) HD_FAIL(c, HD_ERR_INVALID, "hd_eps: bad arguments (n_t must be 1 or batch)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rc = ensure_film_rows(c, n_t);
+    if (rc) return rc;
+    const size_t nlat = (size_t)c->B * 4 * c->L * c->L;
+    HIPCHECK(c, hipMemcpyAsync(c->lat, x, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(c, hipMemsetAsync(c->step_state, 0, sizeof(StepState), s));
+    rc = compute_film(c, timesteps, n_t, s);
+    if (rc) return rc;
+    c->film_step_stride = 0;
+    c->film_face_stride = (n_t == 1) ? 0 : c->film_total;
+    c->advance = 0;
+    rc = run_ops(c, c->program, s, c->op_limit);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpyAsync(eps_out, c->eps, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return HD_OK;
+}
+
+int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* noise, uint64_t seed, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!x_inout || !sched || sched->n_steps <= 0 || !sched->timesteps || !sched->coef) HD_FAIL(c, HD_ERR_INVALID, "hd_sample: bad arguments");
+    HIPCHECK(c, hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int n = sched->n_steps;
+    rc = ensure_film_rows(c, n);
+    if (rc) return rc;
+    if (n > c->coef_cap) {
+        dev_free(c, c->coef_dev);
+        rc = dev_alloc(c, &c->coef_dev, (size_t)n * 7);
+        if (rc) return rc;
+        c->coef_cap = n;
+        if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    }
+    const size_t nlat = (size_t)c->B * 4 * c->L * c->L;
+    // schedule, FiLM table for every step, loop state (step = -1: the intro kernel pre-increments)
+    HIPCHECK(c, hipMemcpyAsync(c->coef_dev, sched->coef, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHECK(c, hipMemcpyAsync(c->t_dev, sched->timesteps, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+    StepState st{};
+    st.step = -1; st.noise = noise; st.seed = seed;
+    HIPCHECK(c, hipMemcpyAsync(c->step_state, &st, sizeof(st), hipMemcpyHostToDevice, s));
+    HIPCHECK(c, hipStreamSynchronize(s));                 // the three host buffers above are caller/stack memory
+    HIPCHECK(c, hipMemcpyAsync(c->lat, x_inout, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    rc = compute_film(c, c->t_dev, n, s);
+    if (rc) return rc;
+    c->film_step_stride = c->film_total;
+    c->film_face_stride = 0;
+    c->advance = 1;
+    if (!c->graph_exec || c->graph_film != c->film_table || c->graph_B != c->B) {
+        if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+        hipStream_t cs;
+        HIPCHECK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            rc = run_ops(c, c->program, cs, -1);
+            if (rc == HD_OK) {
+                hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((nlat + 255) / 256)), dim3(256), 0, cs, c->lat, c->eps, c->coef_dev, c->step_state, (int)nlat);
+            }
+            hipError_t e2 = hipStreamEndCapture(cs, &graph);
+            if (rc == HD_OK && e2 != hipSuccess) { e = e2; }
+        }
+        if (rc == HD_OK && e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipStreamDestroy(cs);
+        if (rc) return rc;
+        if (e != hipSuccess) HD_FAIL(c, HD_ERR_HIP, "graph capture/instantiate failed: %s", hipGetErrorString(e));
+        c->graph_film = c->film_table; c->graph_B = c->B;
+    }
+    if (c->profiling) HIPCHECK(c, hipEventRecord(c->ev0, s));
+    for (int i = 0; i < n; ++i) HIPCHECK(c, hipGraphLaunch(c->graph_exec, s));
+    if (c->profiling) { HIPCHECK(c, hipEventRecord(c->ev1, s)); c->last_steps = n; }
+    HIPCHECK(c, hipMemcpyAsync(x_inout, c->lat, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return HD_OK;
+}
+
+static std::vector<Op>* which_program(hd_ctx* c, int which) { return which == 0 ? &c->program : &c->prep_program; }
+int hd_num_ops(hd_ctx* c, int which) { return c ? (int)which_program(c, which)->size() : 0; }
+int hd_debug_limit_ops(hd_ctx* c, int which, int n) {
+    if (!c) return HD_ERR_INVALID;
+    (which == 0 ? c->op_limit : c->prep_limit) = n;
+    return HD_OK;
+}
+const char* hd_debug_op_name(hd_ctx* c, int which, int i) {
+    if (!c) return "";
+    auto* p = which_program(c, which);
+    return (i >= 0 && i < (int)p->size()) ? (*p)[i].name.c_str() : "";
+}
+static int64_t read_to_host(hd_ctx* c, const void* dev, size_t n, int is_bf16, float* host_out, int64_t max_elems) {
+    if (!host_out) return (int64_t)n;
+    if ((int64_t)n > max_elems) HD_FAIL(c, HD_ERR_INVALID, "debug read needs %zu elements", n);
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipDeviceSynchronize());
+    if (is_bf16) {
+        std::vector<unsigned short> tmp(n);
+        HIPCHECK(c, hipMemcpy(tmp.data(), dev, n * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) { unsigned u = (unsigned)tmp[i] << 16; memcpy(&host_out[i], &u, 4); }
+    } else {
+        HIPCHECK(c, hipMemcpy(host_out, dev, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return (int64_t)n;
+}
+int64_t hd_debug_read_op(hd_ctx* c, int which, int i, float* host_out, int64_t max_elems) {
+    if (!c) return HD_ERR_INVALID;
+    auto* p = which_program(c, which);
+    if (i < 0 || i >= (int)p->size() || !(*p)[i].out) HD_FAIL(c, HD_ERR_INVALID, "no such op %d", i);
+    return read_to_host(c, (*p)[i].out, (*p)[i].out_elems, (*p)[i].out_bf16, host_out, max_elems);
+}
+
+int64_t hd_debug_read(hd_ctx* c, const char* name, float* host_out, int64_t max_elems) {
+    if (!c || !name) return HD_ERR_INVALID;
+    auto it = c->dbg.find(name);
+    if (it == c->dbg.end()) HD_FAIL(c, HD_ERR_INVALID, "unknown debug buffer %s", name);
+    return read_to_host(c, it->second.first, it->second.second.first, it->second.second.second, host_out, max_elems);
+}
+
+int hd_set_profiling(hd_ctx* c, int on) { if (!c) return HD_ERR_INVALID; c->profiling = on != 0; return HD_OK; }
+
+int hd_get_profile(hd_ctx* c, double* loop_ms, double* step_ms_avg, int64_t* weight_bytes_per_step, double* flops_per_face_step) {
+    if (!c) return HD_ERR_INVALID;
+    float ms = 0.f;
+    if (c->profiling && c->last_steps > 0) {
+        HIPCHECK(c, hipEventSynchronize(c->ev1));
+        HIPCHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    }
+    if (loop_ms) *loop_ms = ms;
+    if (step_ms_avg) *step_ms_avg = c->last_steps > 0 ? ms / c->last_steps : 0.0;
+    if (weight_bytes_per_step) *weight_bytes_per_step = c->weight_bytes_per_step;
+    if (flops_per_face_step) *flops_per_face_step = c->flops_per_face_step;
+    return HD_OK;
+}
+
+}  // extern "C"

@@ -97,7 +97,7 @@ def make_state_dict(manifest, seed: int = WEIGHT_SEED, as_torch: bool = True, on
         a = make_tensor(name, shape, kind, fan_in, seed)
         if as_torch:
             import torch
-            a = torch.from_numpy(np.ascontiguousarray(a))
+            a = torch.from_numpy(np.ascontiguousarray(a)).reshape(tuple(shape))   # keeps 0-d tensors 0-d
         out[name] = a
     return out
 

@@ -58,9 +58,10 @@ def _bn_affine(P, p, eps=1e-5):
     return s, o
 
 
-def _conv_bn(x, P, conv, bn, prec, stride=1, padding=0):
+def _conv_bn(x, P, conv, bn, prec, stride=1, padding=0, gemm=True):
     """conv -> BatchNorm(eval).  fp32: in that order (as the reference does); bf16 emulation: BN is
-    folded into the weight and bias first, then the folded weight is rounded (what the packer stores)."""
+    folded into the weight and bias first, then the folded weight is rounded (what the packer stores).
+    gemm=False: the HIP path runs this conv as an fp32 VALU kernel (folded, not rounded)."""
     w = P[conv + ".weight"]
     b = P.get(conv + ".bias")
     if not prec.emulate:
@@ -70,6 +71,8 @@ def _conv_bn(x, P, conv, bn, prec, stride=1, padding=0):
     s, o = _bn_affine(P, bn)
     wf = w * s.view(-1, 1, 1, 1)
     bf = o if b is None else b * s + o
+    if not gemm:
+        return F.conv2d(x, wf, bf, stride=stride, padding=padding)
     return F.conv2d(prec.q(x), prec.q(wf), bf, stride=stride, padding=padding)
 
 
@@ -112,48 +115,67 @@ def film_vectors(P, p, temb):
 
 
 # --------------------------------------------------------------------------------------- NAF blocks
-def _naf_body(P, p, inp, film, prec):
+def _tap(taps, name, x):
+    """Record an intermediate (tests localise a HIP mismatch op by op with these)."""
+    if taps is not None:
+        taps[name] = x
+
+
+def _naf_body(P, p, inp, film, prec, taps=None):
     """Shared body of ConditionalNAFBlock.forward (conditional_naf.py:108-136) and NAFBlock.forward
     (models/fpg/naf.py:105-126); `film` is None for the plain block."""
     x = layernorm2d(inp, P[p + ".norm1.weight"], P[p + ".norm1.bias"])
     if film is not None:
         x = x * (film[1] + 1) + film[0]
     x = _gemm_conv(x, P[p + ".conv1.weight"], P[p + ".conv1.bias"], prec)
+    _tap(taps, p + ".conv1", x)
     c2 = x.shape[1]
     x = F.conv2d(x, P[p + ".conv2.weight"], P[p + ".conv2.bias"], padding=1, groups=c2)  # fp32 VALU
     g = simple_gate(x)
+    _tap(taps, p + ".conv2_gate_pool", g)
     pooled = g.mean(dim=(2, 3), keepdim=True)                       # pooled from the unrounded gate
     s = _gemm_conv(pooled, P[p + ".sca.1.weight"], P[p + ".sca.1.bias"], prec)
+    _tap(taps, p + ".sca", s)
     x = prec.q(g) * s                                               # G is stored bf16 by the HIP path
     x = _gemm_conv(x, P[p + ".conv3.weight"], P[p + ".conv3.bias"], prec)
     y = inp + x * P[p + ".beta"]
+    _tap(taps, p + ".conv3", y)
     x = layernorm2d(y, P[p + ".norm2.weight"], P[p + ".norm2.bias"])
     if film is not None:
         x = x * (film[3] + 1) + film[2]
     x = _gemm_conv(x, P[p + ".conv4.weight"], P[p + ".conv4.bias"], prec)
     x = simple_gate(x)
+    _tap(taps, p + ".conv4", x)
     x = _gemm_conv(x, P[p + ".conv5.weight"], P[p + ".conv5.bias"], prec)
-    return y + x * P[p + ".gamma"]
+    out = y + x * P[p + ".gamma"]
+    _tap(taps, p + ".conv5", out)
+    return out
 
 
-def cond_naf_block(P, p, x, temb, prec=FP32):
-    return _naf_body(P, p, x, film_vectors(P, p, temb), prec)
+def cond_naf_block(P, p, x, temb, prec=FP32, taps=None):
+    return _naf_body(P, p, x, film_vectors(P, p, temb), prec, taps)
 
 
-def naf_block(P, p, x, prec=FP32):
-    return _naf_body(P, p, x, None, prec)
+def naf_block(P, p, x, prec=FP32, taps=None):
+    return _naf_body(P, p, x, None, prec, taps)
 
 
 # --------------------------------------------------------------------------------------- HCA
-def hca_gates(P, p, f_g, prec=FP32):
+def hca_gates(P, p, f_g, prec=FP32, taps=None, tap_name=None):
     """Channel gate w_c (B,C,1,1) and spatial gate w_s (B,1,H,W) of HybridCrossAttention
     (models/fpg/hca.py:33-48).  They depend on the prior only, so the HIP path computes them once."""
     B = f_g.shape[0]
+    tn = tap_name or p
     pooled = (F.adaptive_avg_pool2d(f_g, 1) + F.adaptive_max_pool2d(f_g, 1)).reshape(B, -1)
+    _tap(taps, tn + ".pool", pooled)
     h = torch.relu(_gemm_linear(pooled, P[p + ".channel_mlp.0.weight"], P[p + ".channel_mlp.0.bias"], prec))
+    _tap(taps, tn + ".channel_mlp.0", h)
     w_c = torch.sigmoid(_gemm_linear(h, P[p + ".channel_mlp.2.weight"], P[p + ".channel_mlp.2.bias"], prec))
+    _tap(taps, tn + ".channel_mlp.2", w_c)
     h = torch.relu(_conv_bn(f_g, P, p + ".spatial_mlp.0", p + ".spatial_mlp.1", prec))
-    w_s = torch.sigmoid(_conv_bn(h, P, p + ".spatial_mlp.3", p + ".spatial_mlp.4", prec))
+    _tap(taps, tn + ".spatial_mlp.0", h)
+    w_s = torch.sigmoid(_conv_bn(h, P, p + ".spatial_mlp.3", p + ".spatial_mlp.4", prec, gemm=False))
+    _tap(taps, tn + ".spatial_mlp.3", w_s)
     return w_c.reshape(B, -1, 1, 1), w_s
 
 
@@ -177,20 +199,24 @@ def _up_shuffle(x, w, r, prec):
     return F.pixel_shuffle(y, r) if r > 1 else y
 
 
-def fpg(P, x, prefix="fpg", prec=FP32):
+def fpg(P, x, prefix="fpg", prec=FP32, taps=None):
     """FacialPriorGuidance.forward (models/fpg/model.py:46-64): five prior maps, coarsest first."""
     p = prefix
     x = F.conv2d(x, P[p + ".intro.weight"], P[p + ".intro.bias"], padding=1)      # fp32 direct conv
+    _tap(taps, p + ".intro", x)
     skips = []
     for i, n in enumerate((2, 2, 4, 8)):
         for j in range(n):
-            x = naf_block(P, f"{p}.encoders.{i}.{j}", x, prec)
+            x = naf_block(P, f"{p}.encoders.{i}.{j}", x, prec, taps)
         skips.append(x)
         x = _gemm_conv(x, P[f"{p}.downs.{i}.weight"], P[f"{p}.downs.{i}.bias"], prec, stride=2)
+        _tap(taps, f"{p}.downs.{i}", x)
     x = _up_shuffle(x, P[p + ".convs.0.0.weight"], 1, prec)
+    _tap(taps, p + ".convs.0", x)
     priors = [x]
     for i, skip in zip(range(1, 5), skips[::-1]):
         x = _up_shuffle(x, P[f"{p}.convs.{i}.0.weight"], 2, prec) + skip
+        _tap(taps, f"{p}.convs.{i}", x)
         priors.append(x)
     return priors
 
@@ -201,24 +227,32 @@ def _store(x, prec):
     return prec.q(x)
 
 
-def resnet50(P, x, prefix="idc", prec=FP32):
+def resnet50(P, x, prefix="idc", prec=FP32, taps=None):
     """ResNet.forward / Bottleneck.forward (models/idc/model.py:39-55,122-135): (B,3,128,128) ->
     (B,2048,1,1).  Every conv has a bias and a BatchNorm (eval)."""
     p = prefix
     x = _store(torch.relu(_conv_bn(x, P, p + ".conv1", p + ".batch_norm1", prec, stride=2, padding=3)), prec)
+    _tap(taps, p + ".conv1", x)
     x = F.max_pool2d(x, 3, 2, 1)
+    _tap(taps, p + ".max_pool", x)
     for li, nblk in enumerate((3, 4, 6, 3), start=1):
         for b in range(nblk):
             q = f"{p}.layer{li}.{b}"
             stride = 2 if (b == 0 and li > 1) else 1
             idn = x
             y = _store(torch.relu(_conv_bn(x, P, q + ".conv1", q + ".batch_norm1", prec)), prec)
+            _tap(taps, q + ".conv1", y)
             y = _store(torch.relu(_conv_bn(y, P, q + ".conv2", q + ".batch_norm2", prec, stride=stride, padding=1)), prec)
+            _tap(taps, q + ".conv2", y)
             y = _conv_bn(y, P, q + ".conv3", q + ".batch_norm3", prec)
             if b == 0:
                 idn = _store(_conv_bn(x, P, q + ".i_downsample.0", q + ".i_downsample.1", prec, stride=stride), prec)
+                _tap(taps, q + ".i_downsample", idn)
             x = _store(torch.relu(y + idn), prec)
-    return x.mean(dim=(2, 3), keepdim=True)
+            _tap(taps, q + ".conv3", x)
+    x = x.mean(dim=(2, 3), keepdim=True)
+    _tap(taps, p + ".avgpool", x)
+    return x
 
 
 # --------------------------------------------------------------------------------------- denoiser
@@ -239,16 +273,18 @@ class Conditioning:
     """Step-invariant conditioning of one batch: priors, HCA gates, idc term (hoisted out of the loop;
     the reference recomputes them every step, models/refiner.py:33-34)."""
 
-    def __init__(self, P, cr_latent, cr_face=None, id_emb=None, prec=FP32, prefix="denoiser"):
-        self.priors = fpg(P, cr_latent, "fpg", prec)
+    def __init__(self, P, cr_latent, cr_face=None, id_emb=None, prec=FP32, prefix="denoiser", taps=None):
+        self.priors = fpg(P, cr_latent, "fpg", prec, taps)
         if id_emb is None:
-            id_emb = resnet50(P, cr_face, "idc", prec)
+            id_emb = resnet50(P, cr_face, "idc", prec, taps)
         self.id_emb = id_emb
-        self.gates = [hca_gates(P, f"{prefix}.hcas.{i}", self.priors[i], prec) for i in range(5)]
+        self.gates = [hca_gates(P, f"{prefix}.hcas.{i}", self.priors[i], prec, taps, f"hcas.{i}") for i in range(5)]
         self.idc = _gemm_conv(id_emb, P[prefix + ".idc_conv.weight"], P[prefix + ".idc_conv.bias"], prec)
+        _tap(taps, "idc_conv", self.idc)
 
 
-def fused_denoiser(P, latents, timesteps, priors=None, id_emb=None, prec=FP32, prefix="denoiser", cond=None):
+def fused_denoiser(P, latents, timesteps, priors=None, id_emb=None, prec=FP32, prefix="denoiser", cond=None,
+                   taps=None):
     """FusedDenoiser.forward (models/denoiser/model.py:217-266) -> eps (B,4,L,L).
 
     Either pass `priors` + `id_emb` (the reference signature) or a prepared `Conditioning`."""
@@ -262,22 +298,29 @@ def fused_denoiser(P, latents, timesteps, priors=None, id_emb=None, prec=FP32, p
     else:
         gates, idc = cond.gates, cond.idc
     x = F.conv2d(latents, P[p + ".intro.weight"], P[p + ".intro.bias"], padding=1)
+    _tap(taps, "intro", x)
     skips = []
     for i, n in enumerate((2, 2, 4, 8)):
         for j in range(n):
-            x = cond_naf_block(P, f"{p}.encoders.{i}.{j}", x, temb, prec)
+            x = cond_naf_block(P, f"{p}.encoders.{i}.{j}", x, temb, prec, taps)
         skips.append(x)
         x = _gemm_conv(x, P[f"{p}.downs.{i}.weight"], P[f"{p}.downs.{i}.bias"], prec, stride=2)
+        _tap(taps, f"downs.{i}", x)
     for j in range(8):
-        x = cond_naf_block(P, f"{p}.middle_blks.{j}", x, temb, prec)
+        x = cond_naf_block(P, f"{p}.middle_blks.{j}", x, temb, prec, taps)
     x = x + idc.reshape(B, *x.shape[1:])
     x = hca_apply(P, p + ".hcas.0", gates[0][0], gates[0][1], x, prec)
+    _tap(taps, "hcas.0", x)
     for i, skip in enumerate(skips[::-1]):
         x = _up_shuffle(x, P[f"{p}.ups.{i}.0.weight"], 2, prec) + skip
+        _tap(taps, f"ups.{i}", x)
         for j in range(2):
-            x = cond_naf_block(P, f"{p}.decoders.{i}.{j}", x, temb, prec)
+            x = cond_naf_block(P, f"{p}.decoders.{i}.{j}", x, temb, prec, taps)
         x = hca_apply(P, f"{p}.hcas.{i + 1}", gates[i + 1][0], gates[i + 1][1], x, prec)
-    return F.conv2d(x, P[p + ".ending.weight"], P[p + ".ending.bias"], padding=1)
+        _tap(taps, f"hcas.{i + 1}", x)
+    x = F.conv2d(x, P[p + ".ending.weight"], P[p + ".ending.bias"], padding=1)
+    _tap(taps, "ending", x)
+    return x
 
 
 def refiner_forward(P, latents, timesteps, cr_face, cr_latent, prec=FP32):

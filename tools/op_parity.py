@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Op-by-op parity of the HIP launch programs against the CPU oracle (bf16-emulation mode).
+
+Runs on the GPU box:  python tools/op_parity.py [--batch 2] [--latent 16] [--out gpurun_out/op_parity.txt]
+For every launch of the conditioning prologue and of one denoiser evaluation, the program is run up to
+and including that launch, its output buffer is read back and compared with the oracle's tap of the
+same name.  The first op whose error jumps is the broken one.  (Test infrastructure: uses oracle/.)
+"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hifidiff_amd import _lib, synth                      # noqa: E402
+from hifidiff_amd.refiner import FacialRefiner            # noqa: E402
+from oracle import hifidiff_oracle as O                   # noqa: E402
+
+
+def to_rows(name, t, s):
+    """oracle tap (NCHW) -> the flat layout of the HIP buffer"""
+    if name == "ending":
+        return t.reshape(-1)
+    if name == "idc_conv":
+        B = t.shape[0]
+        return t.reshape(B, 2048, s, s).permute(0, 2, 3, 1).reshape(-1)
+    if t.dim() == 4:
+        return t.permute(0, 2, 3, 1).reshape(-1)
+    return t.reshape(-1)
+
+
+def read_op(L, ctx, which, i):
+    n = L.hd_debug_read_op(ctx, which, i, None, 0)
+    _lib.check(n, ctx)
+    buf = np.empty(n, dtype=np.float32)
+    _lib.check(L.hd_debug_read_op(ctx, which, i, buf.ctypes.data_as(ctypes.c_void_p), n), ctx)
+    return torch.from_numpy(buf)
+
+
+def compare(name, got, ref):
+    if got.numel() != ref.numel():
+        return name, float("nan"), float("nan"), f"size {got.numel()} vs {ref.numel()}"
+    d = (got.double() - ref.double())
+    rel = float(d.norm() / ref.double().norm().clamp_min(1e-30))
+    return name, rel, float(d.abs().max()), ""
+
+
+def scan(model, P, x, crl, crf, t, report, which):
+    L = _lib.lib()
+    e = model.engine
+    taps = {}
+    cond = O.Conditioning(P, crl, crf, prec=O.BF16, taps=taps)
+    O.fused_denoiser(P, x, t, cond=cond, prec=O.BF16, taps=taps)
+    s = e.latent_res // 16
+    worst = 0.0
+    if which == 1:
+        L.hd_debug_limit_ops(e.ctx, 1, -1)
+        e.prepare(crl, cr_face=crf)
+    n = L.hd_num_ops(e.ctx, which)
+    xd = x.cuda()
+    for i in range(n):
+        name = L.hd_debug_op_name(e.ctx, which, i).decode()
+        L.hd_debug_limit_ops(e.ctx, which, i + 1)
+        if which == 1:
+            e.prepare(crl, cr_face=crf)
+        else:
+            e.eps(xd, t)
+        if name not in taps:
+            report.append(f"{which}:{i:3d} {name:45s} (no tap)")
+            continue
+        nm, rel, mx, note = compare(name, read_op(L, e.ctx, which, i), to_rows(name, taps[name], s))
+        flag = "  <<<<<<" if not (rel < 5e-3) else ""
+        worst = max(worst, rel if rel == rel else 1e9)
+        report.append(f"{which}:{i:3d} {name:45s} rel {rel:.3e} maxabs {mx:.3e} {note}{flag}")
+    L.hd_debug_limit_ops(e.ctx, which, -1)
+    if which == 1:
+        e.prepare(crl, cr_face=crf)
+    return worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--latent", type=int, default=16)
+    ap.add_argument("--t", type=float, default=500.0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "op_parity.txt"))
+    a = ap.parse_args()
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    torch.set_grad_enabled(False)
+    t0 = time.time()
+    P = synth.refiner_state_dict(a.latent)
+    print(f"weights {time.time() - t0:.1f}s", flush=True)
+    model = FacialRefiner(a.latent)
+    model.load_state_dict(P)
+    t0 = time.time()
+    model.to("cuda")
+    torch.cuda.synchronize()
+    print(f"upload+pack {time.time() - t0:.1f}s", flush=True)
+    x, crl, crf = synth.sample_inputs(a.batch, a.latent)
+    report = []
+    w1 = scan(model, P, x, crl, crf, a.t, report, 1)
+    print(f"prologue worst rel {w1:.3e}", flush=True)
+    w0 = scan(model, P, x, crl, crf, a.t, report, 0)
+    print(f"step worst rel {w0:.3e}", flush=True)
+    with open(a.out, "w") as f:
+        f.write("\n".join(report) + "\n")
+    bad = [r for r in report if "<<<<<<" in r or "size" in r]
+    print("\n".join(bad[:40]))
+    print(f"{len(bad)} flagged of {len(report)} ops; report in {a.out}")
+
+
+if __name__ == "__main__":
+    main()
