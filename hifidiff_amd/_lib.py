@@ -8,6 +8,12 @@ import ctypes
 import os
 import subprocess
 
+# PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be loaded BEFORE this
+# library so that our DT_NEEDED libamdhip64.so.7 resolves to that same runtime instance: one HIP runtime
+# per process, shared streams and allocations.  Loading ours first pulls in /opt/rocm's copy and the
+# process ends up with two runtimes (torch then reports "No HIP GPUs are available").
+import torch  # noqa: F401  (load order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhifidiff_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_gemm.hpp", "hd_kernels.hpp")]

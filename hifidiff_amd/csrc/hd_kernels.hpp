@@ -60,9 +60,10 @@ __global__ void pack_weight_kernel(const PackP p) {
 // fp32 FMA (K = 36 is too small for MFMA).  The first thread also advances the loop's step counter.
 __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict__ lat, const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ out,
-                                                          int B, int L, StepState* st, int advance) {
+                                                          float2* __restrict__ stats, int B, int L, StepState* st, int advance) {
     __shared__ float wt[36][128];
     __shared__ float patch[16][36];
+    __shared__ float tile[16][128];
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;
     for (int i = threadIdx.x; i < 36 * 128; i += 256) {
         const int co = i / 36, r = i - co * 36;           // w[co][ci][ky][kx], r = ci*9 + tap
@@ -86,12 +87,40 @@ __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict
     const int co = threadIdx.x & 127;
     for (int pl = threadIdx.x >> 7; pl < 16; pl += 2) {
         const int pix = p0 + pl;
-        if (pix >= M) break;
         float acc = b[co];
 #pragma unroll
         for (int r = 0; r < 36; ++r) acc += patch[pl][r] * wt[r][co];
-        out[(size_t)pix * 128 + co] = acc;
+        tile[pl][co] = acc;
+        if (pix < M) out[(size_t)pix * 128 + co] = acc;
     }
+    __syncthreads();
+    // LayerNorm statistics of the 128-channel rows for the first block's norm1: (mean, M2), one partial
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int pl = wave; pl < 16; pl += 4) {
+        const float v0 = tile[pl][lane], v1 = tile[pl][lane + 64];
+        const float mean = wave_sum(v0 + v1) * (1.0f / 128.0f);
+        const float m2 = wave_sum((v0 - mean) * (v0 - mean) + (v1 - mean) * (v1 - mean));
+        if (lane == 0 && p0 + pl < M) stats[p0 + pl] = make_float2(mean, m2);
+    }
+}
+
+// (mean, M2) over the C channels of every row: LayerNorm statistics for tensors whose producer cannot
+// emit them (pixel-shuffled up-conv outputs).  One wave per row.
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, float2* __restrict__ stats, int M, int C) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* rp = X + (size_t)row * C;
+    float s = 0.f;
+    for (int k = lane * 4; k < C; k += 256) { const float4 v = *reinterpret_cast<const float4*>(rp + k); s += (v.x + v.y) + (v.z + v.w); }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int k = lane * 4; k < C; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(rp + k);
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    q = wave_sum(q);
+    if (lane == 0) stats[row] = make_float2(mean, q);
 }
 
 // ending: Conv2d(128,4,3,pad 1) channels-last fp32 -> NCHW eps (models/denoiser/model.py:168-176,261).

@@ -66,7 +66,7 @@ struct Op {
     int out_bf16 = 0;
 };
 
-struct Level { int C, H, M; float *X, *Y, *T1, *pooled, *S; unsigned short* G; };
+struct Level { int C, H, M; float *X, *Y, *T1, *pooled, *S; unsigned short* G; float2 *sx, *sy; };
 
 }  // namespace
 
@@ -100,9 +100,6 @@ struct hd_ctx {
     float *id_emb = nullptr, *pool_tmp = nullptr, *mlp_tmp = nullptr, *sp_tmp = nullptr;
     unsigned short* res_buf[4] = {};
     uint4* face8 = nullptr;
-    float* slab = nullptr;
-    size_t slab_bytes = 0;
-    unsigned* counters = nullptr;
     bool prepared = false;
 
     // FiLM / schedule
@@ -322,61 +319,67 @@ int pack_weight(hd_ctx* c, const std::string& name, PackedW* out, const PackOpts
 }
 
 // ------------------------------------------------------------------------------------ GEMM dispatch
+// mode: 0 = tall T128, 1 = tall T64, 2 = skinny 64 rows, 3 = skinny 32 rows, 4 = tall T32W (32 rows x 256 cols)
 template <class LD, class EP, bool PAIR>
-hipError_t launch_tile(const GemmP& p, bool t128, hipStream_t s) {
-    if constexpr (PAIR) return t128 ? launch_gemm<T128P, LD, EP>(p, s) : launch_gemm<T64P, LD, EP>(p, s);
-    else return t128 ? launch_gemm<T128, LD, EP>(p, s) : launch_gemm<T64, LD, EP>(p, s);
+hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
+    if constexpr (PAIR) {
+        switch (mode) {
+            case 0: return launch_gemm<T128P, LD, EP>(p, s);
+            case 1: return launch_gemm<T64P, LD, EP>(p, s);
+            case 2: return launch_skinny_auto<2, true, LD, EP>(p, s);
+            case 4: return launch_gemm<T32WP, LD, EP>(p, s);
+            default: return launch_skinny_auto<1, true, LD, EP>(p, s);
+        }
+    } else {
+        switch (mode) {
+            case 0: return launch_gemm<T128, LD, EP>(p, s);
+            case 1: return launch_gemm<T64, LD, EP>(p, s);
+            case 2: return launch_skinny_auto<2, false, LD, EP>(p, s);
+            case 4: return launch_gemm<T32W, LD, EP>(p, s);
+            default: return launch_skinny_auto<1, false, LD, EP>(p, s);
+        }
+    }
 }
 
-hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, bool t128, hipStream_t s) {
-    if (lk == LK_LN && ek == EK_BIASF32) return launch_tile<LdF32LN, EpBiasF32, false>(p, t128, s);
-    if (lk == LK_LN && ek == EK_GATE) return launch_tile<LdF32LN, EpGateBF16, true>(p, t128, s);
-    if (lk == LK_F32 && ek == EK_BIASF32) return launch_tile<LdF32Plain, EpBiasF32, false>(p, t128, s);
-    if (lk == LK_F32 && ek == EK_PIXSHUF) return launch_tile<LdF32Plain, EpPixShufF32, false>(p, t128, s);
-    if (lk == LK_BF16S && ek == EK_RESID) return launch_tile<LdBF16Scale, EpResidF32, false>(p, t128, s);
-    if (lk == LK_BF16 && ek == EK_RESID) return launch_tile<LdBF16Plain, EpResidF32, false>(p, t128, s);
-    if (lk == LK_BF16 && ek == EK_BIASBF16) return launch_tile<LdBF16Plain, EpBiasBF16, false>(p, t128, s);
-    if (lk == LK_CONV_F32 && ek == EK_BIASF32) return launch_tile<LdConv<false, false>, EpBiasF32, false>(p, t128, s);
-    if (lk == LK_CONV_F32G && ek == EK_BIASF32) return launch_tile<LdConv<false, true>, EpBiasF32, false>(p, t128, s);
-    if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, t128, s);
+hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStream_t s) {
+    if (lk == LK_LN && ek == EK_BIASF32) return launch_tile<LdF32LN, EpBiasF32, false>(p, mode, s);
+    if (lk == LK_LN && ek == EK_GATE) return launch_tile<LdF32LN, EpGateBF16, true>(p, mode, s);
+    if (lk == LK_F32 && ek == EK_BIASF32) return launch_tile<LdF32Plain, EpBiasF32, false>(p, mode, s);
+    if (lk == LK_F32 && ek == EK_PIXSHUF) return launch_tile<LdF32Plain, EpPixShufF32, false>(p, mode, s);
+    if (lk == LK_BF16S && ek == EK_RESID) return launch_tile<LdBF16Scale, EpResidF32, false>(p, mode, s);
+    if (lk == LK_BF16 && ek == EK_RESID) return launch_tile<LdBF16Plain, EpResidF32, false>(p, mode, s);
+    if (lk == LK_BF16 && ek == EK_BIASBF16) return launch_tile<LdBF16Plain, EpBiasBF16, false>(p, mode, s);
+    if (lk == LK_CONV_F32 && ek == EK_BIASF32) return launch_tile<LdConv<false, false>, EpBiasF32, false>(p, mode, s);
+    if (lk == LK_CONV_F32G && ek == EK_BIASF32) return launch_tile<LdConv<false, true>, EpBiasF32, false>(p, mode, s);
+    if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, mode, s);
     return hipErrorInvalidValue;
 }
 
-// Tile + split-K choice: fill >= 256 workgroups (256 CUs), keep >= 2 K-chunks per slice.
-void choose_tiling(hd_ctx* c, GemmP& p, bool pair, bool* t128) {
+// Kernel choice: tall tiles while they still give >= 256 workgroups (256 CUs); otherwise the skinny
+// kernel (one 32-column weight tile per workgroup, K split across its waves), with 32-row groups when
+// 64-row groups would leave most of the chip idle.
+int choose_mode(const GemmP& p, bool pair) {
     const int ncols = pair ? p.N / 2 : p.N;
-    const int nb = (ncols + 63) / 64;
-    const int mb128 = (p.M + 127) / 128, mb64 = (p.M + 63) / 64;
-    *t128 = (mb128 * nb >= 256);
-    const int wgs = (*t128 ? mb128 : mb64) * nb;
-    const int chunks = p.Kp / 64;
-    int ks = 1;
-    if (!*t128) {
-        for (int cand = 2; cand <= chunks; ++cand) {
-            if (chunks % cand) continue;
-            if (chunks / cand < 2) break;
-            if (wgs * cand > 512) break;
-            ks = cand;
-            if (wgs * cand >= 256) break;
-        }
-    }
-    const size_t per = (size_t)(pair ? 2 : 1) * 64 * 64 * sizeof(float);
-    if ((size_t)wgs * ks * per > c->slab_bytes || wgs > 8192) ks = 1;
-    p.ksplit = ks;
-    p.slab = c->slab;
-    p.counters = c->counters;
+    const int nb64 = (ncols + 63) / 64, nb32 = (ncols + 31) / 32;
+    static const int force = getenv("HD_GEMM_MODE") ? atoi(getenv("HD_GEMM_MODE")) : -1;
+    if (force >= 0) return force;
+    const int nb256 = (ncols + (pair ? 127 : 255)) / (pair ? 128 : 256);
+    if (p.Kp <= 256 && nb256 <= 2 && ((p.M + 31) / 32) * nb256 >= 512) return 4;   // levels 0/1 at full batch
+    if (((p.M + 127) / 128) * nb64 >= 256) return 0;
+    if (((p.M + 63) / 64) * nb64 >= 256) return 1;
+    if (((p.M + 63) / 64) * nb32 >= 192) return 2;
+    return 3;
 }
 
 GemmP base_gemm(const PackedW& w, int M) {
     GemmP p{};
     p.M = M; p.N = w.N; p.K = w.K; p.Kp = w.Kp; p.nt_total = w.nt_total; p.W = w.w; p.bias = w.bias;
-    p.ksplit = 1; p.a_scale = 1.f; p.hw = 1; p.ln_eps = 1e-6f; p.shuffle_r = 1;
+    p.a_scale = 1.f; p.hw = 1; p.ln_eps = 1e-6f; p.shuffle_r = 1; p.stats_np = 1; p.stats_cnt = 1;
     return p;
 }
 
 void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p, LdKind lk, EpKind ek) {
-    bool t128 = false;
-    choose_tiling(c, p, ek == EK_GATE, &t128);
+    const int t128 = choose_mode(p, ek == EK_GATE);          // (kernel mode; name kept for the capture list)
     const bool film = (lk == LK_LN);
     size_t out_rows = (size_t)p.M * (ek == EK_PIXSHUF ? p.shuffle_r * p.shuffle_r : 1);
     Op op;
@@ -397,7 +400,10 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
 
 // One (Conditional)NAFBlock on level buffers (conditional_naf.py:108-136 / naf.py:105-126), six launches.
 // static_film: FPG blocks use the LayerNorm affine itself as the "FiLM" row (scale = shift = 0).
-void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Level& lv, const float* static_film) {
+// x_np/x_cnt: how the LayerNorm partials of the block input X were produced (C/32 x 32 by a GEMM
+// epilogue, 1 x C by intro / row_stats); on return they describe conv5's output.
+void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Level& lv, const float* static_film, int* x_np,
+                   int* x_cnt) {
     const int C = bw.C, M = lv.M, HW = lv.H * lv.H;
     auto film_fields = [&](GemmP& p, int half) {
         p.hw = HW;
@@ -409,6 +415,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
     {   // LN1 + FiLM -> conv1 (+bias) -> T1
         GemmP p = base_gemm(bw.conv1, M);
         p.A = lv.X; p.lda = C; film_fields(p, 0);
+        p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
         p.out = lv.T1; p.ldo = 2 * C;
         add_gemm(c, prog, bw.name + ".conv1", p, LK_LN, EK_BIASF32);
     }
@@ -431,11 +438,13 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         GemmP p = base_gemm(bw.conv3, M);
         p.A = lv.G; p.lda = C; p.hw = HW; p.rowscale = lv.S;
         p.out = lv.Y; p.ldo = C; p.resid = lv.X; p.ldr = C; p.rscale = bw.beta;
+        p.stats_out = lv.sy;
         add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16S, EK_RESID);
     }
     {   // LN2 + FiLM -> conv4 -> SimpleGate -> G2 (bf16, reuses G)
         GemmP p = base_gemm(bw.conv4, M);
         p.A = lv.Y; p.lda = C; film_fields(p, 1);
+        p.stats_in = lv.sy; p.stats_np = C / 32; p.stats_cnt = 32;
         p.out = lv.G; p.ldo = C;
         add_gemm(c, prog, bw.name + ".conv4", p, LK_LN, EK_GATE);
     }
@@ -443,15 +452,27 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         GemmP p = base_gemm(bw.conv5, M);
         p.A = lv.G; p.lda = C;
         p.out = lv.X; p.ldo = C; p.resid = lv.Y; p.ldr = C; p.rscale = bw.gamma;
+        p.stats_out = lv.sx;
         add_gemm(c, prog, bw.name + ".conv5", p, LK_BF16, EK_RESID);
     }
+    *x_np = C / 32; *x_cnt = 32;
+}
+
+void add_row_stats(std::vector<Op>& prog, const std::string& name, const float* X, float2* stats, int M, int C) {
+    Op op;
+    op.name = name;
+    op.run = [=](hipStream_t s) -> hipError_t {
+        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, stats, M, C);
+        return hipGetLastError();
+    };
+    prog.push_back(op);
 }
 
 void add_down(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const Level& src, const Level& dst) {
     GemmP p = base_gemm(w, dst.M);                      // Conv2d(C, 2C, 2, 2) as a patch-gather GEMM
     p.A = src.X; p.lda = src.C; p.Hin = src.H; p.Win = src.H; p.Cin = src.C; p.KH = 2; p.KW = 2; p.stride = 2; p.pad = 0;
     p.Hout = dst.H; p.Wout = dst.H; p.ntaps = 4;
-    p.out = dst.X; p.ldo = dst.C;
+    p.out = dst.X; p.ldo = dst.C; p.stats_out = dst.sx;
     add_gemm(c, prog, name, p, LK_CONV_F32, EK_BIASF32);
 }
 
@@ -498,6 +519,7 @@ int alloc_workspace(hd_ctx* c, int B) {
         const size_t mc = (size_t)v.M * v.C;
         rc |= dev_alloc(c, &v.X, mc); rc |= dev_alloc(c, &v.Y, mc); rc |= dev_alloc(c, &v.T1, 2 * mc);
         rc |= dev_alloc(c, &v.G, mc); rc |= dev_alloc(c, &v.pooled, (size_t)B * v.C); rc |= dev_alloc(c, &v.S, (size_t)B * v.C);
+        rc |= dev_alloc(c, &v.sx, (size_t)v.M * (v.C / 32)); rc |= dev_alloc(c, &v.sy, (size_t)v.M * (v.C / 32));
         const int pi = 4 - l;                            // prior index: coarsest first
         rc |= dev_alloc(c, &c->prior[pi], mc); rc |= dev_alloc(c, &c->gate_c[pi], (size_t)B * v.C);
         rc |= dev_alloc(c, &c->gate_s[pi], (size_t)v.M);
@@ -534,28 +556,32 @@ int build_denoiser_program(hd_ctx* c) {
     const RawTensor *iw = find_raw(c, "denoiser.intro.weight"), *ib = find_raw(c, "denoiser.intro.bias");
     const RawTensor *ew = find_raw(c, "denoiser.ending.weight"), *eb = find_raw(c, "denoiser.ending.bias");
     {
-        const float *lat = c->lat, *w = iw->dev, *b = ib->dev; float* out = c->lv[0].X;
+        const float *lat = c->lat, *w = iw->dev, *b = ib->dev; float* out = c->lv[0].X; float2* sx = c->lv[0].sx;
         const int M = c->lv[0].M;
         prog.push_back({"intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, lat, w, b, out, B, L, c->step_state, c->advance);
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, lat, w, b, out, sx, B, L, c->step_state, c->advance);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
     }
     const int enc[4] = {2, 2, 4, 8};
     int bi = 0;
+    int np = 1, cnt = WIDTH;                            // intro emits one (mean, M2) partial per row
     for (int l = 0; l < 4; ++l) {
-        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->lv[l], nullptr);
+        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->lv[l], nullptr, &np, &cnt);
         add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->lv[l], c->lv[l + 1]);
+        np = c->lv[l + 1].C / 32; cnt = 32;
     }
-    for (int j = 0; j < 8; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->lv[4], nullptr);
+    for (int j = 0; j < 8; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->lv[4], nullptr, &np, &cnt);
     // x + idc_conv(id) -> HCA0 (model.py:245-247); the add is folded into the HCA loader
     add_hca(c, prog, "hcas.0", c->hca[0], 0, c->lv[4].X, c->idc_term, c->lv[4].Y, c->lv[4].M, c->lv[4].H);
     for (int i = 0; i < 4; ++i) {
         const int l = 3 - i;
         const Level &hi = c->lv[l + 1], &lo = c->lv[l];
         add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], hi.Y, hi.M, hi.H, hi.C, lo.X, lo.X, 2);
-        for (int j = 0; j < 2; ++j) add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr);
+        add_row_stats(prog, "ups." + std::to_string(i) + ".row_stats", lo.X, lo.sx, lo.M, lo.C);
+        np = 1; cnt = lo.C;
+        for (int j = 0; j < 2; ++j) add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt);
         add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], i + 1, lo.X, nullptr, lo.Y, lo.M, lo.H);
     }
     {
@@ -606,18 +632,20 @@ void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
     const int B = c->B, L = c->L;
     const RawTensor *iw = find_raw(c, "fpg.intro.weight"), *ib = find_raw(c, "fpg.intro.bias");
     {
-        const float *w = iw->dev, *b = ib->dev; float* out = c->lv[0].X; const int M = c->lv[0].M;
+        const float *w = iw->dev, *b = ib->dev; float* out = c->lv[0].X; const int M = c->lv[0].M; float2* sx = c->lv[0].sx;
         prog.push_back({"fpg.intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, cr_latent_dev, w, b, out, B, L, c->step_state, 0);
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, cr_latent_dev, w, b, out, sx, B, L, c->step_state, 0);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
     }
     const int enc[4] = {2, 2, 4, 8};
     int bi = 0;
+    int np = 1, cnt = WIDTH;
     for (int l = 0; l < 4; ++l) {
-        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->fpg_blocks[bi++], c->lv[l], c->fpg_ln_pack);
+        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->fpg_blocks[bi++], c->lv[l], c->fpg_ln_pack, &np, &cnt);
         add_down(c, prog, "fpg.downs." + std::to_string(l), c->fpg_down[l], c->lv[l], c->lv[l + 1]);
+        np = c->lv[l + 1].C / 32; cnt = 32;
     }
     // convs[0]: 1x1, PixelShuffle(1) == identity -> prior0; then 4x (1x1, PixelShuffle(2), + enc skip)
     add_up(c, prog, "fpg.convs.0", c->fpg_convs[0], c->lv[4].X, c->lv[4].M, c->lv[4].H, c->lv[4].C, c->prior[0], nullptr, 1);
@@ -747,13 +775,9 @@ int hd_create(hd_ctx** out, int latent_res, int device) {
     }
     hd_ctx* c = new hd_ctx();
     c->L = latent_res; c->device = device; c->S = latent_res / 16;
-    c->slab_bytes = (size_t)64 << 20;
-    int rc = dev_alloc(c, &c->slab, c->slab_bytes / sizeof(float));
-    if (!rc) rc = dev_alloc(c, &c->counters, 8192);
-    if (!rc) rc = dev_alloc(c, &c->step_state, 1);
+    int rc = dev_alloc(c, &c->step_state, 1);
     if (!rc) rc = dev_alloc(c, &c->freq_dev, 64);
     if (rc) { g_create_error = c->err; hd_destroy(c); return rc; }
-    (void)hipMemset(c->counters, 0, 8192 * sizeof(unsigned));
     (void)hipMemset(c->step_state, 0, sizeof(StepState));
     float freq[64];
     const float e = (float)(-(std::log(10000.0) / 63.0));       // model.py:25: python double, then fp32 tensor math
