@@ -1,25 +1,27 @@
-// hd_gemm.hpp — the one MFMA GEMM / implicit-conv kernel family of the refiner path (gfx950 only).
+// hd_gemm.hpp — the MFMA GEMM / implicit-conv kernel family of the refiner path (gfx950 only).
 //
 //   Out[M,N] = epilogue( loader(A)[M,K] * W[K,N] )        bf16 operands, fp32 accumulate
 //
 // * rows  = pixels (channels-last activations, row = (face, y, x)), cols = output channels.
-// * W is pre-packed once (hd_pack.hpp) in MFMA B-fragment order: [N/32][K/16][64 lanes][8 bf16], so a
-//   wave streams its weight tiles with fully coalesced 1 KiB loads straight into registers — no LDS
-//   round trip for the operand that is read exactly once (the HBM-bound levels 3/mid).
-// * A is staged global -> registers -> (loader transform, bf16) -> LDS, double buffered, one barrier
-//   per 64-deep K chunk; rows are padded to 144 B so the ds_read_b128 fragment reads are conflict-free.
+// * W is pre-packed once (hd_kernels.hpp: pack_weight_kernel) in MFMA B-fragment order
+//   [N/32][K/16][64 lanes][8 bf16], so a wave streams its weight tiles with fully coalesced 1 KiB loads
+//   straight into registers — no LDS round trip for the operand that is read exactly once.
+// * A is loaded in whole cache lines (8 lanes per row; fp32 sources as two 128-byte halves per row so
+//   that every wave-load covers complete lines), transformed by the loader, converted to bf16 and staged
+//   through LDS in rows padded to 144 B (conflict-free ds_read_b128 fragment reads).
 // * The loader fuses what precedes the conv in the reference: LayerNorm2d + FiLM (utils.py:16-24,
 //   conditional_naf.py:114-115), the SCA channel scale (conditional_naf.py:119), the HCA gate
 //   (hca.py:28) and the im2col gather of the 2x2/3x3/7x7 convs.
-// * The epilogue fuses what follows: bias, SimpleGate (utils.py:57-60; the wave computes column tile j
-//   and tile j+N/2 so the product is register-local), beta/gamma residual (conditional_naf.py:123,134),
-//   PixelShuffle + skip add (models/denoiser/model.py:204-208,256-257), BN(eval)+ReLU.
+// * The epilogue fuses what follows: bias, SimpleGate (utils.py:57-60; a wave computes column tile j and
+//   tile j+N/2 so the product is register-local), beta/gamma residual (conditional_naf.py:123,134),
+//   PixelShuffle + skip add (models/denoiser/model.py:204-208,256-257), BN(eval)+ReLU, and for conv1 the
+//   whole depthwise 3x3 + SimpleGate + SCA average pool (conditional_naf.py:116-119) on the LDS tile.
 // * Two kernels share the loaders/epilogues:
-//     gemm_kernel        tall M (levels 0/1, ResNet): A staged through LDS, waves tile M x N.
-//     gemm_skinny_kernel small M (levels 2..mid, gates): one 32-column weight tile per workgroup, the
-//                        waves split K inside the workgroup (A fragments straight to registers, partial
-//                        tiles summed through LDS in wave order: bitwise deterministic, no inter-workgroup
-//                        protocol), so a 64 x 2048 x 4096 GEMM still spreads over the chip.
+//     gemm_kernel        tall M (levels 0/1 at full batch, ResNet): workgroup-shared LDS tile, waves tile M x N.
+//     gemm_skinny_kernel small M: one 32-column weight tile per workgroup; its waves split M (WM) and K (WK);
+//                        every wave stages its own A sub-tile in a private LDS region (no barrier in the
+//                        K loop); partial tiles are summed through LDS in wave order (bitwise
+//                        deterministic, no inter-workgroup protocol).
 // * LayerNorm statistics are never recomputed by the consumer: every producer of a residual-stream
 //   tensor emits per-row (mean, M2) partials per 32-column tile (stats_out), and the LN loader merges
 //   them with Chan's parallel-variance update.
@@ -32,7 +34,7 @@ namespace hd {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-constexpr int BK = 64;                 // K chunk staged per barrier
+constexpr int BK = 64;                 // K chunk
 constexpr int LDS_ROW = BK * 2 + 16;   // bytes per staged A row (128 B data + 16 B pad)
 
 struct GemmP {
@@ -67,7 +69,25 @@ struct GemmP {
     int ldr;
     int act;                      // 0 none, 1 relu, 2 sigmoid
     int shuffle_r;                // pixel-shuffle factor (1 or 2)
+    // fused depthwise 3x3 + SimpleGate + average pool (EpDwGate)
+    const float* dw_w;            // [N][9]
+    const float* dw_b;            // [N]
+    float* pooled;                // [faces][N/2]
+    int side;                     // face side (hw = side*side)
+#ifdef HD_STAMPS
+    unsigned long long* stamps;   // diagnostic build (tools/gemm_bench): [workgroup][8] s_memrealtime ticks (100 MHz)
+#endif
 };
+
+#ifdef HD_STAMPS
+#define HD_STAMP(i)                                                                                     \
+    do {                                                                                                \
+        if (p.stamps && threadIdx.x == 0)                                                               \
+            p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define HD_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     unsigned short a = __builtin_bit_cast(unsigned short, (__bf16)lo);
@@ -87,54 +107,74 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short v) { return __u
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// In-wave reductions on the DPP cross-lane path (a few cycles each).  __shfl_xor lowers to ds_bpermute, an
+// LDS-latency operation: ten dependent ones per row made the statistics epilogue cost 11 us per kernel.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// every lane gets the sum over its 16-lane row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
     return v;
 }
-
-template <int WM_, int WN_, int MT_, int TN_, bool PAIR_>
-struct Cfg {
-    static constexpr int WM = WM_, WN = WN_, MT = MT_, TN = TN_;
-    static constexpr bool PAIR = PAIR_;
-    static constexpr int WAVES = WM * WN;
-    static constexpr int THREADS = 64 * WAVES;
-    static constexpr int BM = WM * MT * 32;
-    static constexpr int TNT = PAIR ? 2 * TN : TN;
-    static constexpr int NCOLS = WN * TN * 32;          // (gate) columns per workgroup
-    static constexpr int UNITS = BM * 8 / THREADS;      // (row, 8 k) staging units per thread
-    static constexpr int A_BUF = BM * LDS_ROW;
-    static constexpr int STATS_OFF = 2 * A_BUF;
-    static constexpr int GB_OFF = STATS_OFF + BM * 8;      // + 2*Kp floats of FiLM gain/bias for the LN loader
-    static constexpr int SMEM = GB_OFF;
-    static_assert(UNITS >= 1 && UNITS * THREADS == BM * 8, "tile/threads mismatch");
-};
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// row_bcast15: lane 15 of rows 0/2 is added into every lane of rows 1/3 -> after row16_sum the lanes
+// 16..31 and 48..63 hold the sum over their 32-lane half (all 64 lanes must be active)
+__device__ __forceinline__ float halfwave_sum_hi(float v) {
+    v = row16_sum(v);
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = halfwave_sum_hi(v);                                   // lanes 16-31: half 0, lanes 48-63: half 1
+    return lane_value(v, 31) + lane_value(v, 63);
+}
 
 // ------------------------------------------------------------------------------------------ loaders
+// A "unit" is what one lane stages per 64-deep chunk for one row: 8 k-values.
+//   kSplit == false (bf16 sources): k = kc + 8*kq + {0..7}            -> one 16-byte LDS write at 16*kq
+//   kSplit == true  (fp32 sources): k = kc + 4*kq + {0..3} and kc + 32 + 4*kq + {0..3}: the 8 lanes of a
+//       row read two complete 128-byte lines                           -> two 8-byte LDS writes (8*kq, 64 + 8*kq)
+// fetch() issues the global loads, finish() transforms and packs (lo 4 | hi 4).  kc >= K yields zeros.
 struct F8 { float4 a, b; };
-__device__ __forceinline__ F8 ldg8(const float* p) {
-    F8 r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); return r;
+__device__ __forceinline__ F8 ldg44(const float* p) {             // 4 floats at p, 4 floats at p + 32
+    F8 r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 32); return r;
 }
 __device__ __forceinline__ F8 zero8() { F8 r; r.a = make_float4(0, 0, 0, 0); r.b = r.a; return r; }
 __device__ __forceinline__ void f8_to_arr(const F8& x, float* v) {
     v[0] = x.a.x; v[1] = x.a.y; v[2] = x.a.z; v[3] = x.a.w; v[4] = x.b.x; v[5] = x.b.y; v[6] = x.b.z; v[7] = x.b.w;
 }
+template <bool SPLIT>
+__device__ __forceinline__ void lds_write_unit(char* row_base, int kq, uint4 v) {
+    if (SPLIT) {
+        *reinterpret_cast<uint2*>(row_base + 8 * kq) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(row_base + 64 + 8 * kq) = make_uint2(v.z, v.w);
+    } else {
+        *reinterpret_cast<uint4*>(row_base + 16 * kq) = v;
+    }
+}
 
 // fp32 rows, optional scalar scale (SCA pooled input, up-conv input, gate MLPs)
 struct LdF32Plain {
+    static constexpr int kRawRegs = 8;
+    static constexpr bool kGainBiasLds = false, kSplit = true;
     struct St { const float* rowp; bool valid; };
     struct Raw { F8 x; };
-    static constexpr int kRawRegs = 8;
-    static constexpr bool kGainBiasLds = false;
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
         st.rowp = reinterpret_cast<const float*>(p.A) + (size_t)(st.valid ? row : 0) * p.lda;
     }
-    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int k0, Raw& r) {
-        r.x = (st.valid && k0 < p.K) ? ldg8(st.rowp + k0) : zero8();
+    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
+        r.x = (st.valid && kc < p.K) ? ldg44(st.rowp + kc + 4 * kq) : zero8();
     }
-    static __device__ __forceinline__ uint4 finish(const GemmP& p, const St&, int, const Raw& r) {
+    static __device__ __forceinline__ uint4 finish(const GemmP& p, const St&, int, int, const Raw& r) {
         float v[8]; f8_to_arr(r.x, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= p.a_scale;
@@ -142,11 +182,12 @@ struct LdF32Plain {
     }
 };
 
-// fp32 rows -> LayerNorm2d over the row (two-pass, biased variance, eps inside the sqrt: utils.py:18-22)
-// -> folded LN-affine/FiLM gain and bias (conditional_naf.py:114-115,126-127)
+// fp32 rows -> LayerNorm2d over the row (biased variance, eps inside the sqrt: utils.py:18-22) -> folded
+// LN-affine/FiLM gain and bias (conditional_naf.py:114-115,126-127).  Row statistics come from the
+// producer's partials.
 struct LdF32LN {
     static constexpr int kRawRegs = 8;
-    static constexpr bool kGainBiasLds = true;
+    static constexpr bool kGainBiasLds = true, kSplit = true;
     struct St { const float* rowp; const float* gain; const float* bias; const float* gbl; float mu, rstd; bool valid; };
     struct Raw { F8 x; };
     // (1) merge the producer's per-tile (mean, M2) partials of each row into (mean, rstd) in LDS: 4 threads
@@ -179,8 +220,10 @@ struct LdF32LN {
                 }
             }
 #pragma unroll
-            for (int o = 1; o < 4; o <<= 1) {
-                const float n2 = __shfl_xor(n, o, 64), mean2 = __shfl_xor(mean, o, 64), m22 = __shfl_xor(m2, o, 64);
+            for (int o = 1; o < 4; o <<= 1) {                       // butterfly over the quad: lane ^ 1, lane ^ 2
+                const float n2 = (o == 1) ? dpp_mov<0xB1>(n) : dpp_mov<0x4E>(n);
+                const float mean2 = (o == 1) ? dpp_mov<0xB1>(mean) : dpp_mov<0x4E>(mean);
+                const float m22 = (o == 1) ? dpp_mov<0xB1>(m2) : dpp_mov<0x4E>(m2);
                 const float nn = n + n2;
                 if (nn > 0.f) {
                     const float d = mean2 - mean;
@@ -205,21 +248,16 @@ struct LdF32LN {
         st.gain = f + p.film_gain_off;
         st.bias = f + p.film_bias_off;
     }
-    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int k0, Raw& r) {
-        r.x = (st.valid && k0 < p.K) ? ldg8(st.rowp + k0) : zero8();
+    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
+        r.x = (st.valid && kc < p.K) ? ldg44(st.rowp + kc + 4 * kq) : zero8();
     }
-    static __device__ __forceinline__ uint4 finish(const GemmP& p, const St& st, int k0, const Raw& r) {
+    static __device__ __forceinline__ uint4 finish(const GemmP& p, const St& st, int kc, int kq, const Raw& r) {
         float v[8], g[8], b[8];
-        if (!(st.valid && k0 < p.K)) return make_uint4(0, 0, 0, 0);
+        if (!(st.valid && kc < p.K)) return make_uint4(0, 0, 0, 0);
         f8_to_arr(r.x, v);
-        if (st.gbl) {
-            const float4* gp = reinterpret_cast<const float4*>(st.gbl + k0);
-            const float4* bp = reinterpret_cast<const float4*>(st.gbl + p.Kp + k0);
-            F8 gg, bb; gg.a = gp[0]; gg.b = gp[1]; bb.a = bp[0]; bb.b = bp[1];
-            f8_to_arr(gg, g); f8_to_arr(bb, b);
-        } else {
-            f8_to_arr(ldg8(st.gain + k0), g); f8_to_arr(ldg8(st.bias + k0), b);
-        }
+        const int k = kc + 4 * kq;
+        if (st.gbl) { f8_to_arr(ldg44(st.gbl + k), g); f8_to_arr(ldg44(st.gbl + p.Kp + k), b); }
+        else { f8_to_arr(ldg44(st.gain + k), g); f8_to_arr(ldg44(st.bias + k), b); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (v[i] - st.mu) * st.rstd * g[i] + b[i];
         return pack8(v);
@@ -228,27 +266,27 @@ struct LdF32LN {
 
 // bf16 rows, copied as they are (conv5 input G2, ResNet 1x1 convs)
 struct LdBF16Plain {
+    static constexpr int kRawRegs = 4;
+    static constexpr bool kGainBiasLds = false, kSplit = false;
     struct St { const unsigned short* rowp; bool valid; };
     struct Raw { uint4 x; };
-    static constexpr int kRawRegs = 4;
-    static constexpr bool kGainBiasLds = false;
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
         st.rowp = reinterpret_cast<const unsigned short*>(p.A) + (size_t)(st.valid ? row : 0) * p.lda;
     }
-    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int k0, Raw& r) {
-        r.x = (st.valid && k0 < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + k0) : make_uint4(0, 0, 0, 0);
+    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
+        r.x = (st.valid && kc < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
     }
-    static __device__ __forceinline__ uint4 finish(const GemmP&, const St&, int, const Raw& r) { return r.x; }
+    static __device__ __forceinline__ uint4 finish(const GemmP&, const St&, int, int, const Raw& r) { return r.x; }
 };
 
 // bf16 rows times a per-(face, k) fp32 scale: x * sca(x) feeding conv3 (conditional_naf.py:119-120)
 struct LdBF16Scale {
+    static constexpr int kRawRegs = 12;
+    static constexpr bool kGainBiasLds = false, kSplit = false;
     struct St { const unsigned short* rowp; const float* srow; bool valid; };
     struct Raw { uint4 x; F8 s; };
-    static constexpr int kRawRegs = 12;
-    static constexpr bool kGainBiasLds = false;
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
@@ -256,26 +294,31 @@ struct LdBF16Scale {
         st.rowp = reinterpret_cast<const unsigned short*>(p.A) + (size_t)r * p.lda;
         st.srow = p.rowscale + (size_t)(r / p.hw) * p.K;
     }
-    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int k0, Raw& r) {
-        if (st.valid && k0 < p.K) { r.x = *reinterpret_cast<const uint4*>(st.rowp + k0); r.s = ldg8(st.srow + k0); }
-        else { r.x = make_uint4(0, 0, 0, 0); r.s = zero8(); }
+    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
+        const bool ok = st.valid && kc < p.K;
+        r.x = ok ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
+        F8 s;
+        s.a = ok ? *reinterpret_cast<const float4*>(st.srow + kc + 8 * kq) : make_float4(0, 0, 0, 0);
+        s.b = ok ? *reinterpret_cast<const float4*>(st.srow + kc + 8 * kq + 4) : make_float4(0, 0, 0, 0);
+        r.s = s;
     }
-    static __device__ __forceinline__ uint4 finish(const GemmP&, const St&, int, const Raw& r) {
-        float v[8], s[8]; unpack8(r.x, v); f8_to_arr(r.s, s);
+    static __device__ __forceinline__ uint4 finish(const GemmP&, const St&, int, int, const Raw& r) {
+        float v[8], sc[8]; unpack8(r.x, v); f8_to_arr(r.s, sc);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= s[i];
+        for (int i = 0; i < 8; ++i) v[i] *= sc[i];
         return pack8(v);
     }
 };
 
-// im2col gather over a channels-last image: k = tap*Cin + c.  SRC_BF16: ResNet activations;
-// fp32 + GATED: the HCA 3x3 conv input f_d*(1 + w_c + w_s) (+ idc term) (hca.py:28, model.py:245-246)
+// im2col gather over a channels-last image: k = tap*Cin + c.  SRC_BF16: ResNet activations (8 consecutive
+// k per lane); fp32 (4 + 4 split, each half resolved to its own tap);
+// GATED: the HCA 3x3 conv input f_d*(1 + w_c + w_s) (+ idc term) (hca.py:28, model.py:245-246)
 template <bool SRC_BF16, bool GATED>
 struct LdConv {
+    static constexpr int kRawRegs = (SRC_BF16 ? 4 : 8) + (GATED ? 18 : 0) + 2;
+    static constexpr bool kGainBiasLds = false, kSplit = !SRC_BF16;
     struct St { int b, iy0, ix0; bool valid; };
-    struct Raw { F8 x; F8 add; F8 gc; float gs; uint4 xb; bool inb; };
-    static constexpr int kRawRegs = (SRC_BF16 ? 4 : 8) + (GATED ? 17 : 0) + 1;
-    static constexpr bool kGainBiasLds = false;
+    struct Raw { float4 x[2]; float4 add[2]; float4 gc[2]; float gs[2]; uint4 xb; bool inb[2]; };
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
@@ -287,122 +330,211 @@ struct LdConv {
         st.iy0 = oy * p.stride - p.pad;
         st.ix0 = (rem - oy * p.Wout) * p.stride - p.pad;
     }
-    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int k0, Raw& r) {
-        const int tap = k0 / p.Cin;
-        const int c0 = k0 - tap * p.Cin;
+    // source row index of (tap-resolved) k; returns false if padding / out of range
+    static __device__ __forceinline__ bool locate(const GemmP& p, const St& st, int k, size_t& srow, int& c0) {
+        const int tap = k / p.Cin;
+        c0 = k - tap * p.Cin;
         const int ky = tap / p.KW;
         const int iy = st.iy0 + ky, ix = st.ix0 + (tap - ky * p.KW);
-        r.inb = st.valid && tap < p.ntaps && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-        if (!r.inb) return;
-        const size_t srow = ((size_t)st.b * p.Hin + iy) * p.Win + ix;
+        const bool ok = st.valid && tap < p.ntaps && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        srow = ok ? ((size_t)st.b * p.Hin + iy) * p.Win + ix : 0;
+        return ok;
+    }
+    static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
         if (SRC_BF16) {
-            r.xb = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.A) + srow * p.Cin + c0);
+            size_t srow; int c0;
+            r.inb[0] = locate(p, st, kc + 8 * kq, srow, c0);
+            if (r.inb[0]) r.xb = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.A) + srow * p.Cin + c0);
         } else {
-            r.x = ldg8(reinterpret_cast<const float*>(p.A) + srow * p.Cin + c0);
-        }
-        if (GATED) {
-            r.gs = p.gate_s[srow];
-            r.gc = ldg8(p.gate_c + (size_t)st.b * p.Cin + c0);
-            r.add = p.add_src ? ldg8(p.add_src + srow * p.Cin + c0) : zero8();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                size_t srow; int c0;
+                r.inb[h] = locate(p, st, kc + 32 * h + 4 * kq, srow, c0);
+                if (!r.inb[h]) continue;
+                r.x[h] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.A) + srow * p.Cin + c0);
+                if (GATED) {
+                    r.gs[h] = p.gate_s[srow];
+                    r.gc[h] = *reinterpret_cast<const float4*>(p.gate_c + (size_t)st.b * p.Cin + c0);
+                    r.add[h] = p.add_src ? *reinterpret_cast<const float4*>(p.add_src + srow * p.Cin + c0) : make_float4(0, 0, 0, 0);
+                }
+            }
         }
     }
-    static __device__ __forceinline__ uint4 finish(const GemmP&, const St&, int, const Raw& r) {
-        if (!r.inb) return make_uint4(0, 0, 0, 0);
-        if (SRC_BF16 && !GATED) return r.xb;
+    static __device__ __forceinline__ uint4 finish(const GemmP&, const St&, int, int, const Raw& r) {
+        if (SRC_BF16) return r.inb[0] ? r.xb : make_uint4(0, 0, 0, 0);
         float v[8];
-        if (SRC_BF16) unpack8(r.xb, v); else f8_to_arr(r.x, v);
-        if (GATED) {
-            float a[8], g[8]; f8_to_arr(r.add, a); f8_to_arr(r.gc, g);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (v[i] + a[i]) * (1.0f + g[i] + r.gs);
+        for (int h = 0; h < 2; ++h) {
+            float4 x = r.inb[h] ? r.x[h] : make_float4(0, 0, 0, 0);
+            if (GATED && r.inb[h]) {
+                const float4 a = r.add[h], g = r.gc[h];
+                const float s = 1.0f + r.gs[h];
+                x.x = (x.x + a.x) * (s + g.x); x.y = (x.y + a.y) * (s + g.y);
+                x.z = (x.z + a.z) * (s + g.z); x.w = (x.w + a.w) * (s + g.w);
+            }
+            v[4 * h] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
         }
         return pack8(v);
     }
 };
 
 // ---------------------------------------------------------------------------------------- epilogues
+// Protocol (element-wise epilogues): per output column the lane loads its constants once (col_init); the
+// loads that may alias `out` in the compiler's eyes (residual / skip tensors) are issued for the whole
+// tile first (pre), then all stores follow — otherwise every store->load pair is serialised by a
+// vmcnt(0) wait (measured: 4.6 us per kernel).
 __device__ __forceinline__ float activate(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return 1.0f / (1.0f + expf(-v));
     return v;
 }
+struct ColC { float bias, bias2, rscale; };
 
 // out(fp32)[row][col] = act(acc + bias)
 struct EpBiasF32 {
-    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v) {
-        if (p.bias) v += p.bias[col];
-        v = activate(v, p.act);
+    static constexpr bool kStats = true, kTile = false;
+    static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias ? p.bias[col] : 0.f; c.bias2 = 0.f; c.rscale = 1.f; return c; }
+    static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
+    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float, const ColC& c) {
+        v = activate(v + c.bias, p.act);
         reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
         return v;
     }
 };
 // out(fp32) = resid + rscale[col] * (acc + bias)      (y = inp + x*beta, out = y + x*gamma)
 struct EpResidF32 {
-    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v) {
-        v += p.bias[col];
-        const float r = reinterpret_cast<const float*>(p.resid)[(size_t)row * p.ldr + col];
-        v = r + v * p.rscale[col];
+    static constexpr bool kStats = true, kTile = false;
+    static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = 0.f; c.rscale = p.rscale[col]; return c; }
+    static __device__ __forceinline__ float pre(const GemmP& p, int row, int col) {
+        return reinterpret_cast<const float*>(p.resid)[(size_t)row * p.ldr + col];
+    }
+    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float r, const ColC& c) {
+        v = r + (v + c.bias) * c.rscale;
         reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
         return v;
     }
 };
 // PAIR: out(bf16)[row][col] = (acc1 + bias[col]) * (acc2 + bias[col + N/2])   (conv4 -> SimpleGate)
 struct EpGateBF16 {
-    static __device__ __forceinline__ void store2(const GemmP& p, int row, int col, float v1, float v2) {
-        v1 += p.bias[col]; v2 += p.bias[col + (p.N >> 1)];
-        reinterpret_cast<unsigned short*>(p.out)[(size_t)row * p.ldo + col] = f32_to_bf16_bits(v1 * v2);
+    static constexpr bool kStats = false, kTile = false;
+    static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = p.bias[col + (p.N >> 1)]; c.rscale = 1.f; return c; }
+    static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
+    static __device__ __forceinline__ void store2(const GemmP& p, int row, int col, float v1, float v2, const ColC& c) {
+        reinterpret_cast<unsigned short*>(p.out)[(size_t)row * p.ldo + col] = f32_to_bf16_bits((v1 + c.bias) * (v2 + c.bias2));
     }
 };
 // 1x1 conv (no bias) -> PixelShuffle(r) -> + skip : out[b, r*h+i, r*w+j, c] = acc[n = c*r*r + i*r + j]
 struct EpPixShufF32 {
-    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v) {
-        float* out = reinterpret_cast<float*>(p.out);
-        size_t o;
+    static constexpr bool kStats = false, kTile = false;
+    static __device__ __forceinline__ ColC col_init(const GemmP&, int) { ColC c; c.bias = 0.f; c.bias2 = 0.f; c.rscale = 1.f; return c; }
+    static __device__ __forceinline__ size_t index(const GemmP& p, int row, int col) {
         if (p.shuffle_r == 2) {
             const int hw = p.Hin * p.Win;
             const int b = row / hw, rem = row - b * hw;
             const int h = rem / p.Win, w = rem - h * p.Win;
             const int c = col >> 2, i = (col >> 1) & 1, j = col & 1;
-            o = (((size_t)b * (2 * p.Hin) + (2 * h + i)) * (2 * p.Win) + (2 * w + j)) * p.ldo + c;
-        } else {
-            o = (size_t)row * p.ldo + col;
+            return (((size_t)b * (2 * p.Hin) + (2 * h + i)) * (2 * p.Win) + (2 * w + j)) * p.ldo + c;
         }
-        if (p.resid) v += reinterpret_cast<const float*>(p.resid)[o];
-        out[o] = v;
+        return (size_t)row * p.ldo + col;
+    }
+    static __device__ __forceinline__ float pre(const GemmP& p, int row, int col) {
+        return p.resid ? reinterpret_cast<const float*>(p.resid)[index(p, row, col)] : 0.f;
+    }
+    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float r, const ColC&) {
+        v += r;
+        reinterpret_cast<float*>(p.out)[index(p, row, col)] = v;
         return v;
     }
 };
 // out(bf16) = act(acc + bias (+ resid bf16))           (ResNet conv+BN(+identity)+ReLU, BN folded)
 struct EpBiasBF16 {
-    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v) {
-        v += p.bias[col];
-        if (p.resid) v += bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.resid)[(size_t)row * p.ldr + col]);
-        v = activate(v, p.act);
+    static constexpr bool kStats = false, kTile = false;
+    static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = 0.f; c.rscale = 1.f; return c; }
+    static __device__ __forceinline__ float pre(const GemmP& p, int row, int col) {
+        return p.resid ? bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.resid)[(size_t)row * p.ldr + col]) : 0.f;
+    }
+    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float r, const ColC& c) {
+        v = activate(v + c.bias + r, p.act);
         reinterpret_cast<unsigned short*>(p.out)[(size_t)row * p.ldo + col] = f32_to_bf16_bits(v);
         return v;
     }
 };
+// PAIR, skinny kernel only: the workgroup's T1 tile (conv1 output of whole faces, channels j and j+N/2)
+// stays in LDS; depthwise 3x3 (pad 1) on both halves, SimpleGate, G (bf16) and the per-face average pool
+// (conditional_naf.py:116-119 / naf.py:109-112).  Needs BM % hw == 0.
+struct EpDwGate {
+    static constexpr bool kStats = false, kTile = true;
+    static __device__ __forceinline__ ColC col_init(const GemmP&, int) { ColC c; c.bias = 0.f; c.bias2 = 0.f; c.rscale = 1.f; return c; }
+    static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
+    static __device__ __forceinline__ void store2(const GemmP&, int, int, float, float, const ColC&) {}
+};
 
-// ------------------------------------------------------------------------------ statistics emission
-// (mean, M2) of 32 values spread over the 32 lanes of a half-wave (Chan partial for one 32-column tile)
+// LayerNorm partial of one 32-column tile: the 32 values of a row sit in the 32 lanes of a half-wave.
+// Single pass (sum, sum of squares); the result is valid in lanes 16..31 / 48..63 (kStatLane).
+constexpr int kStatLane = 16;
 __device__ __forceinline__ float2 halfwave_mean_m2(float v) {
-    float s = v;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s * (1.0f / 32.0f);
-    float d = v - mean;
-    d *= d;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-    return make_float2(mean, d);
+    const float s1 = halfwave_sum_hi(v), s2 = halfwave_sum_hi(v * v);
+    const float mean = s1 * (1.0f / 32.0f);
+    return make_float2(mean, fmaxf(s2 - s1 * mean, 0.f));
 }
 
-// Does this epilogue's store() return the value it wrote (needed to emit LN statistics of `out`)?
-template <class EP> struct EpTraits { static constexpr bool kStats = false; };
-template <> struct EpTraits<EpBiasF32> { static constexpr bool kStats = true; };
-template <> struct EpTraits<EpResidF32> { static constexpr bool kStats = true; };
+// Epilogue of one 32x32 accumulator tile in MFMA layout (col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)).
+// FULL: the tile lies completely inside [M) x [ncols) (wave-uniform) -> no per-element predicates, so the
+// 16 loads, 16 stores and the statistics math are emitted as straight-line batches.
+template <bool FULL, bool PAIR, class EP>
+__device__ __forceinline__ void tile_epilogue_mfma(const GemmP& p, const f32x16_t& a1, const f32x16_t& a2, int rbase, int col,
+                                                   int ncols, int tile_idx, int lane) {
+    const bool cv = FULL || col < ncols;
+    const ColC cc = EP::col_init(p, cv ? col : 0);
+    float pre[16], v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = rbase + (i & 3) + 8 * (i >> 2);
+        pre[i] = (FULL || (cv && row < p.M)) ? EP::pre(p, row, col) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = rbase + (i & 3) + 8 * (i >> 2);
+        v[i] = 0.f;
+        if (FULL || (cv && row < p.M)) {
+            if constexpr (PAIR) EP::store2(p, row, col, a1[i], a2[i], cc);
+            else v[i] = EP::store(p, row, col, a1[i], pre[i], cc);
+        }
+    }
+    if constexpr (EP::kStats) {
+        if (p.stats_out) {                                     // rows of `out` feed a LayerNorm next
+            float2 ms[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ms[i] = halfwave_mean_m2(v[i]);
+            if ((lane & 31) == kStatLane) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = rbase + (i & 3) + 8 * (i >> 2);
+                    if (FULL || row < p.M) p.stats_out[(size_t)row * (p.N >> 5) + tile_idx] = ms[i];
+                }
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------- tall kernel
+template <int WM_, int WN_, int MT_, int TN_, bool PAIR_>
+struct Cfg {
+    static constexpr int WM = WM_, WN = WN_, MT = MT_, TN = TN_;
+    static constexpr bool PAIR = PAIR_;
+    static constexpr int WAVES = WM * WN;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int BM = WM * MT * 32;
+    static constexpr int TNT = PAIR ? 2 * TN : TN;
+    static constexpr int NCOLS = WN * TN * 32;          // (gate) columns per workgroup
+    static constexpr int UNITS = BM * 8 / THREADS;      // (row, 8 k) staging units per thread
+    static constexpr int A_BUF = BM * LDS_ROW;
+    static constexpr int STATS_OFF = 2 * A_BUF;
+    static constexpr int GB_OFF = STATS_OFF + BM * 8;   // + 2*Kp floats of FiLM gain/bias for the LN loader
+    static constexpr int SMEM = GB_OFF;
+    static_assert(UNITS >= 1 && UNITS * THREADS == BM * 8, "tile/threads mismatch");
+};
+
 template <class C, class LD, class EP>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -412,7 +544,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
     const int ksteps_total = p.Kp >> 4;
     const int c_end = p.Kp >> 6;
 
-    // weight tiles of this wave
     int tile[C::TNT];
 #pragma unroll
     for (int tn = 0; tn < C::TN; ++tn) {
@@ -422,17 +553,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
     }
     const int tiles_half = C::PAIR ? (p.N >> 6) : p.nt_total;
 
+    HD_STAMP(0);
     float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + C::GB_OFF) : nullptr;
     LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
 
     typename LD::St st[C::UNITS];
-    int u_ldsoff[C::UNITS], u_k[C::UNITS];
+    int u_ldsoff[C::UNITS];
+    const int kq = tid & 7;
 #pragma unroll
     for (int u = 0; u < C::UNITS; ++u) {
-        const int unit = tid + u * C::THREADS;
-        const int rl = unit >> 3, kq = unit & 7;
-        u_ldsoff[u] = rl * LDS_ROW + kq * 16;
-        u_k[u] = kq * 8;
+        const int rl = (tid >> 3) + u * (C::THREADS / 8);
+        u_ldsoff[u] = rl * LDS_ROW;
         LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
     }
 
@@ -457,16 +588,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
                             : make_uint4(0, 0, 0, 0);                                                 \
     }
 #define HD_FETCH_A(chunk)                                                                             \
-    _Pragma("unroll") for (int u = 0; u < C::UNITS; ++u) LD::fetch(p, st[u], (chunk) * BK + u_k[u], raw[u]);
+    _Pragma("unroll") for (int u = 0; u < C::UNITS; ++u) LD::fetch(p, st[u], (chunk) * BK, kq, raw[u]);
 #define HD_WRITE_A(chunk, buf)                                                                        \
     _Pragma("unroll") for (int u = 0; u < C::UNITS; ++u)                                              \
-        *reinterpret_cast<uint4*>(smem + (buf) * C::A_BUF + u_ldsoff[u]) =                            \
-            LD::finish(p, st[u], (chunk) * BK + u_k[u], raw[u]);
+        lds_write_unit<LD::kSplit>(smem + (buf) * C::A_BUF + u_ldsoff[u], kq, LD::finish(p, st[u], (chunk) * BK, kq, raw[u]));
 
     HD_FETCH_A(0);
     HD_LOAD_B(bcur, 0);
+    HD_STAMP(1);
     HD_WRITE_A(0, 0);
     __syncthreads();
+    HD_STAMP(2);
 
     const int a_lane_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
     for (int c = 0; c < c_end; ++c) {
@@ -504,63 +636,107 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
 #undef HD_LOAD_B
 #undef HD_FETCH_A
 #undef HD_WRITE_A
+    HD_STAMP(3);
+    HD_STAMP(4);
 
-    // ---- epilogue: C/D map of mfma_f32_32x32x16: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5) ----
+    // ---- epilogue ----
     const int ncols = C::PAIR ? (p.N >> 1) : p.N;
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt) {
-        const int rbase = row0 + (w_m * C::MT + mt) * 32 + 4 * (lane >> 5);
+        const int rtile = row0 + (w_m * C::MT + mt) * 32;
+        const int rbase = rtile + 4 * (lane >> 5);
 #pragma unroll
         for (int tn = 0; tn < C::TN; ++tn) {
-            const int col = tile[tn] * 32 + (lane & 31);
             if (tile[tn] * 32 >= ncols) continue;                      // wave-uniform
+            const int col = tile[tn] * 32 + (lane & 31);
+            const bool full = (rtile + 32 <= p.M) && (tile[tn] * 32 + 32 <= ncols);   // wave-uniform
+            if (full) tile_epilogue_mfma<true, C::PAIR, EP>(p, acc[mt][tn], acc[mt][C::PAIR ? C::TN + tn : tn], rbase, col, ncols, tile[tn], lane);
+            else tile_epilogue_mfma<false, C::PAIR, EP>(p, acc[mt][tn], acc[mt][C::PAIR ? C::TN + tn : tn], rbase, col, ncols, tile[tn], lane);
+        }
+    }
+    HD_STAMP(5);
+}
+
+// ----------------------------------------------------------------------------------- skinny kernel
+template <int WM_, int WK_, int MT_, bool PAIR_, int D_>
+struct SkinnyCfg {
+    static constexpr int WM = WM_, WK = WK_, MT = MT_, D = D_;
+    static constexpr int WAVES = WM * WK, THREADS = 64 * WAVES, BM = WM * MT * 32, TNT = PAIR_ ? 2 : 1;
+    static constexpr int UN = MT * 4;                            // (row, 8 k) units per lane per chunk
+    static constexpr int A_WAVE = MT * 32 * LDS_ROW;             // private staging tile of one wave
+    static constexpr int RED = WK * BM * 32 * TNT * 4;           // [wk][tn][row][32] partial tiles (aliases staging)
+    static constexpr int STAGE = (WAVES * A_WAVE > RED) ? WAVES * A_WAVE : RED;
+    static constexpr int GT_OFF = STAGE;                         // EpDwGate: gate tile [BM][32] fp32
+    static constexpr int STATS_OFF = GT_OFF + BM * 32 * 4;
+    static constexpr int GB_OFF = STATS_OFF + BM * 8;            // + 2*Kp floats of gain/bias for the LN loader
+};
+
+template <bool FULL, class C, class EP>
+__device__ __forceinline__ void skinny_rows_epilogue(const GemmP& p, const float* red, int row0, int col, int ncols, int tile_idx, int tid) {
+    constexpr int NIT = (C::BM * 32 + C::THREADS - 1) / C::THREADS, TNT = C::TNT, WK = C::WK;
+    constexpr int TILE_F = C::BM * 32 * TNT;
+    constexpr bool EVEN = (C::BM * 32) % C::THREADS == 0;
+    const bool cv = FULL || col < ncols;
+    const ColC cc = EP::col_init(p, cv ? col : 0);
+    float pre[NIT], v[NIT];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = rbase + (i & 3) + 8 * (i >> 2);
-                float v = 0.f;
-                if (row < p.M && col < ncols) {
-                    if constexpr (C::PAIR) EP::store2(p, row, col, acc[mt][tn][i], acc[mt][C::TN + tn][i]);
-                    else v = EP::store(p, row, col, acc[mt][tn][i]);
-                }
-                if constexpr (EpTraits<EP>::kStats) {
-                    if (p.stats_out) {                                 // rows of `out` feed a LayerNorm next
-                        const float2 ms = halfwave_mean_m2(v);
-                        if ((lane & 31) == 0 && row < p.M) p.stats_out[(size_t)row * (p.N >> 5) + tile[tn]] = ms;
-                    }
+    for (int it = 0; it < NIT; ++it) {
+        const int e = it * C::THREADS + tid;
+        const int row = row0 + (e >> 5);
+        const bool ok = (EVEN || e < C::BM * 32) && (FULL || (row < p.M && cv));
+        pre[it] = ok ? EP::pre(p, row, col) : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = it * C::THREADS + tid;
+        const int row = row0 + (e >> 5);
+        const bool ev = EVEN || e < C::BM * 32;
+        float v1 = 0.f, v2 = 0.f;
+        if (ev) {
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                v1 += red[w * TILE_F + e];
+                if (TNT == 2) v2 += red[w * TILE_F + C::BM * 32 + e];
+            }
+        }
+        v[it] = 0.f;
+        if (ev && (FULL || (row < p.M && cv))) {
+            if constexpr (TNT == 2) EP::store2(p, row, col, v1, v2, cc);
+            else v[it] = EP::store(p, row, col, v1, pre[it], cc);
+        }
+    }
+    if constexpr (EP::kStats) {
+        if (p.stats_out) {
+            float2 ms[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) ms[it] = halfwave_mean_m2(v[it]);
+            if ((tid & 31) == kStatLane) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int e = it * C::THREADS + tid;
+                    const int row = row0 + (e >> 5);
+                    if ((EVEN || e < C::BM * 32) && (FULL || row < p.M)) p.stats_out[(size_t)row * (p.N >> 5) + tile_idx] = ms[it];
                 }
             }
         }
     }
 }
 
-// ----------------------------------------------------------------------------------- skinny kernel
-// One 32-column weight tile (PAIR: tile j and tile j + N/64) x MT*32 rows per workgroup; the K dimension
-// is split over the workgroup's WAVES waves (wave w owns k-steps [w*ksw, (w+1)*ksw)).  A fragments come
-// straight from global memory in MFMA layout (lane (r,h) holds A[row r][k0 + 8h .. +8] = one loader
-// unit), B fragments from the packed weight.  Each wave issues G k-steps of loads in one burst (two
-// bursts in flight), so with ksw <= 2G the whole K-slice of a wave is requested up front: the kernel is
-// one memory round trip deep instead of K/32.  Partial tiles are summed through LDS in wave order.
-template <int MT, int WAVES, bool PAIR, int G_>
-struct SkinnyCfg {
-    static constexpr int THREADS = 64 * WAVES, BM = MT * 32, TNT = PAIR ? 2 : 1, G = G_;
-    static constexpr int RED = WAVES * BM * 32 * TNT * 4;        // cross-wave reduction buffer (bytes)
-    static constexpr int STATS_OFF = RED;
-    static constexpr int GB_OFF = STATS_OFF + BM * 8;            // + 2*Kp floats of gain/bias for the LN loader
-};
-
 template <class C, class LD, class EP>
 __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = C::BM / 32, TNT = C::TNT, WAVES = C::THREADS / 64, G = C::G;
+    constexpr int MT = C::MT, TNT = C::TNT, WK = C::WK, D = C::D, UN = C::UN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WK, wk = wave - wm * WK;
     const int row0 = blockIdx.x * C::BM;
     const int ksteps_total = p.Kp >> 4;
-    const int ksw = ksteps_total / WAVES;                    // host: Kp % (16*WAVES) == 0
-    const int ks0 = wave * ksw, ks_end = ks0 + ksw;
+    const int cpw = (p.Kp >> 6) / WK;                        // host: Kp % (64*WK) == 0
+    const int c0 = wk * cpw, c_end = c0 + cpw;
     int tile[TNT];
     tile[0] = blockIdx.y;
     if (TNT == 2) tile[1] = blockIdx.y + (p.N >> 6);
     const uint4* Wl = p.W + lane;
+    HD_STAMP(0);
 
     f32x16_t acc[MT][TNT];
 #pragma unroll
@@ -570,97 +746,160 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][tn][i] = 0.f;
 
-    // weights of the first burst go out before anything that waits (statistics merge, row setup)
-    uint4 bq[2][G][TNT];
-#define HD_SK_LOAD_B(slot, ks)                                                                         \
-    _Pragma("unroll") for (int g = 0; g < G; ++g) _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn)   \
-        bq[slot][g][tn] = ((ks) + g < ks_end) ? Wl[((size_t)tile[tn] * ksteps_total + (ks) + g) * 64] : make_uint4(0, 0, 0, 0);
-    HD_SK_LOAD_B(0, ks0);
+    uint4 bq[D][4][TNT];
+    typename LD::Raw aq[D][UN];
+#define HD_SK_LOAD_B(slot, chunk)                                                                      \
+    _Pragma("unroll") for (int ss = 0; ss < 4; ++ss) _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn) \
+        bq[slot][ss][tn] = ((chunk) < c_end) ? Wl[((size_t)tile[tn] * ksteps_total + (chunk) * 4 + ss) * 64] : make_uint4(0, 0, 0, 0);
+    // weights first: they do not depend on anything this kernel has to wait for
+#pragma unroll
+    for (int d = 0; d < D; ++d) { HD_SK_LOAD_B(d, c0 + d); }
 
     float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + C::GB_OFF) : nullptr;
     LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
-    typename LD::St st[MT];
+    typename LD::St st[UN];
+    int u_off[UN];
+    const int kq = lane & 7;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        LD::unit_init(p, st[mt], row0 + mt * 32 + (lane & 31), mt * 32 + (lane & 31), smem + C::STATS_OFF, gb);
-    const int k_lane = 8 * (lane >> 5);
-
-    typename LD::Raw aq[2][G][MT];
-#define HD_SK_K(ks, g) (((ks) + (g) < ks_end) ? ((ks) + (g)) * 16 + k_lane : p.Kp)
-#define HD_SK_FETCH_A(slot, ks)                                                                        \
-    _Pragma("unroll") for (int g = 0; g < G; ++g) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)    \
-        LD::fetch(p, st[mt], HD_SK_K(ks, g), aq[slot][g][mt]);
-#define HD_SK_COMPUTE(slot, ks)                                                                        \
-    _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                    \
-        bf16x8_t a[MT];                                                                                \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
-            a[mt] = __builtin_bit_cast(bf16x8_t, LD::finish(p, st[mt], HD_SK_K(ks, g), aq[slot][g][mt])); \
-        _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) \
-            acc[mt][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], __builtin_bit_cast(bf16x8_t, bq[slot][g][tn]), acc[mt][tn], 0, 0, 0); \
+    for (int u = 0; u < UN; ++u) {
+        const int rw = (lane >> 3) + 8 * u;                      // row inside the wave's MT*32-row sub-tile
+        const int rl = wm * MT * 32 + rw;
+        u_off[u] = rw * LDS_ROW;
+        LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
     }
-    HD_SK_FETCH_A(0, ks0);
-    for (int ks = ks0; ks < ks_end; ks += 2 * G) {            // two bursts per trip: static register slots
-        if (ks + G < ks_end) { HD_SK_LOAD_B(1, ks + G); HD_SK_FETCH_A(1, ks + G); }
-        HD_SK_COMPUTE(0, ks);
-        if (ks + G < ks_end) {
-            if (ks + 2 * G < ks_end) { HD_SK_LOAD_B(0, ks + 2 * G); HD_SK_FETCH_A(0, ks + 2 * G); }
-            HD_SK_COMPUTE(1, ks + G);
+#define HD_SK_FETCH_A(slot, chunk)                                                                     \
+    _Pragma("unroll") for (int u = 0; u < UN; ++u)                                                     \
+        LD::fetch(p, st[u], ((chunk) < c_end) ? (chunk) * BK : p.Kp, kq, aq[slot][u]);
+#pragma unroll
+    for (int d = 0; d < D; ++d) { HD_SK_FETCH_A(d, c0 + d); }
+    HD_STAMP(1);
+
+    char* sA = smem + wave * C::A_WAVE;
+    const int a_lane_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
+    for (int cb = c0; cb < c_end; cb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int cc = cb + d;
+            if (cc < c_end) {                                      // wave-uniform
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+                    lds_write_unit<LD::kSplit>(sA + u_off[u], kq, LD::finish(p, st[u], cc * BK, kq, aq[d][u]));
+                __builtin_amdgcn_wave_barrier();                   // LDS ops of one wave execute in order
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) {
+                    bf16x8_t a[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[mt] = *reinterpret_cast<const bf16x8_t*>(sA + a_lane_off + (mt * 32) * LDS_ROW + ss * 32);
+#pragma unroll
+                    for (int tn = 0; tn < TNT; ++tn)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                a[mt], __builtin_bit_cast(bf16x8_t, bq[d][ss][tn]), acc[mt][tn], 0, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+                HD_SK_LOAD_B(d, cc + D);
+                HD_SK_FETCH_A(d, cc + D);
+                if (cc == c0) HD_STAMP(2);
+            }
         }
     }
 #undef HD_SK_LOAD_B
 #undef HD_SK_FETCH_A
-#undef HD_SK_COMPUTE
-#undef HD_SK_K
+    HD_STAMP(3);
 
-    // ---- cross-wave reduction through LDS, in wave order; then a row-major epilogue ----
+    // ---- partial tiles to LDS: red[wk][tn][row in BM][32] ----
+    __syncthreads();                                           // staging tiles are dead: reuse as reduction buffer
+    HD_STAMP(4);
     float* red = reinterpret_cast<float*>(smem);
-    constexpr int TILE_F = C::BM * 32 * TNT;                  // floats per wave partial, layout [tn][row][col]
+    constexpr int TILE_F = C::BM * 32 * TNT;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int tn = 0; tn < TNT; ++tn)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int r = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                red[wave * TILE_F + (tn * C::BM + r) * 32 + (lane & 31)] = acc[mt][tn][i];
+                const int r = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                red[wk * TILE_F + (tn * C::BM + r) * 32 + (lane & 31)] = acc[mt][tn][i];
             }
     __syncthreads();
     const int ncols = (TNT == 2) ? (p.N >> 1) : p.N;
     const int col = tile[0] * 32 + (tid & 31);
-    for (int e0 = 0; e0 < C::BM * 32; e0 += C::THREADS) {      // e -> (row_local, col_local): 32 lanes = one row
-        const int e = e0 + tid;
-        const bool ev = e < C::BM * 32;
-        const int row = row0 + (e >> 5);
-        float v1 = 0.f, v2 = 0.f;
-        if (ev) {
+
+    if constexpr (EP::kTile) {
+        // ================= conv1 bias -> depthwise 3x3 -> SimpleGate -> G, pooled =================
+        static_assert(TNT == 2, "EpDwGate needs a PAIR tile");
+        const int C2 = p.N >> 1;
+        // (1) sum the K-split partials in wave order, add conv1's bias, keep T1 in slice 0
+        for (int e = tid; e < C::BM * 32; e += C::THREADS) {
+            const bool rv = (row0 + (e >> 5)) < p.M && col < ncols;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                v1 += red[w * TILE_F + e];
-                if (TNT == 2) v2 += red[w * TILE_F + C::BM * 32 + e];
+            for (int tn = 0; tn < 2; ++tn) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WK; ++w) v += red[w * TILE_F + tn * C::BM * 32 + e];
+                v += rv ? p.bias[col + tn * C2] : 0.f;
+                red[tn * C::BM * 32 + e] = rv ? v : 0.f;
             }
         }
-        float v = 0.f;
-        if (ev && row < p.M && col < ncols) {
-            if constexpr (TNT == 2) EP::store2(p, row, col, v1, v2);
-            else v = EP::store(p, row, col, v1);
+        __syncthreads();
+        // (2) depthwise 3x3 (pad 1) on both halves from LDS, gate, store G (bf16); gate tile to LDS
+        float* gt = reinterpret_cast<float*>(smem + C::GT_OFF);
+        const int j = tid & 31, pg = tid >> 5;
+        const int S = p.side, HW = p.hw;
+        float wa[9], wb[9], ba = 0.f, bb = 0.f;
+        if (col < ncols) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { wa[t] = p.dw_w[(size_t)col * 9 + t]; wb[t] = p.dw_w[(size_t)(col + C2) * 9 + t]; }
+            ba = p.dw_b[col]; bb = p.dw_b[col + C2];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { wa[t] = 0.f; wb[t] = 0.f; }
         }
-        if constexpr (EpTraits<EP>::kStats) {
-            if (p.stats_out) {
-                const float2 ms = halfwave_mean_m2(v);
-                if (ev && (tid & 31) == 0 && row < p.M) p.stats_out[(size_t)row * (p.N >> 5) + tile[0]] = ms;
+        for (int pr = pg; pr < C::BM; pr += C::THREADS / 32) {
+            const int q = pr % HW, fbase = pr - q;
+            const int y = q / S, x = q - y * S;
+            float u1 = ba, u2 = bb;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy < 0 || yy >= S || xx < 0 || xx >= S) continue;
+                const int pp = fbase + yy * S + xx;
+                u1 += wa[t] * red[pp * 32 + j];
+                u2 += wb[t] * red[(C::BM + pp) * 32 + j];
             }
+            const float g = u1 * u2;
+            gt[pr * 32 + j] = g;
+            const int row = row0 + pr;
+            if (row < p.M && col < ncols) reinterpret_cast<unsigned short*>(p.out)[(size_t)row * p.ldo + col] = f32_to_bf16_bits(g);
         }
+        __syncthreads();
+        // (3) per-face average pool of the unrounded gate (SCA input)
+        const int faces = C::BM / HW;
+        for (int idx = tid; idx < faces * 32; idx += C::THREADS) {
+            const int f = idx >> 5;
+            float s = 0.f;
+            for (int q = 0; q < HW; ++q) s += gt[(f * HW + q) * 32 + j];
+            const int face = row0 / HW + f;
+            if (face * HW < p.M && col < ncols) p.pooled[(size_t)face * C2 + col] = s / (float)HW;
+        }
+    } else {
+        // ================= element-wise epilogue, 32 lanes = one row of the tile =================
+        const bool full = (row0 + C::BM <= p.M) && (tile[0] * 32 + 32 <= ncols);      // workgroup-uniform
+        if (full) skinny_rows_epilogue<true, C, EP>(p, red, row0, col, ncols, tile[0], tid);
+        else skinny_rows_epilogue<false, C, EP>(p, red, row0, col, ncols, tile[0], tid);
     }
+    HD_STAMP(5);
 }
 
-// Tile shapes.  T128: tall GEMMs (levels 0/1, ResNet) — 4 waves stacked along M, each 32 rows x 64 cols.
-//               T64 : 2x2 waves, 64 rows x 64 cols.
+// Tile shapes of the tall kernel.
+//   T128: 4 waves stacked along M, each 32 rows x 64 cols.     T64: 2x2 waves, 64 rows x 64 cols.
+//   T32W: 32 rows x (4 waves x 64 cols): the whole N of a level-0 GEMM in one workgroup.
 typedef Cfg<4, 1, 1, 2, false> T128;
 typedef Cfg<4, 1, 1, 1, true> T128P;
 typedef Cfg<2, 2, 1, 1, false> T64;
 typedef Cfg<2, 2, 1, 1, true> T64P;
-//               T32W: 32 rows x (4 waves x 64 cols): the whole N of a level-0/1 GEMM in one workgroup, so the
-//               activation tile is read once and >= 512 small workgroups keep the CUs occupied.
 typedef Cfg<1, 4, 1, 2, false> T32W;
 typedef Cfg<1, 4, 1, 1, true> T32WP;
 
@@ -669,12 +908,12 @@ inline hipError_t launch_gemm(const GemmP& p, hipStream_t s) {
     const int ncols = C::PAIR ? p.N / 2 : p.N;
     const int smem = C::SMEM + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0);
     if (smem > 65536) {                                      // above the default dynamic-LDS limit
-        static int granted = 0;
-        if (smem > granted) {
+        static bool granted = false;
+        if (!granted) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C, LD, EP>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            granted = 160 * 1024;
+            granted = true;
         }
     }
     dim3 grid((p.M + C::BM - 1) / C::BM, (ncols + C::NCOLS - 1) / C::NCOLS, 1);
@@ -685,14 +924,14 @@ inline hipError_t launch_gemm(const GemmP& p, hipStream_t s) {
 template <class C, class LD, class EP>
 inline hipError_t launch_skinny(const GemmP& p, hipStream_t s) {
     const int smem = C::GB_OFF + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0);
-    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    if (smem > 160 * 1024 || (p.Kp / 64) % C::WK != 0) return hipErrorInvalidValue;
     if (smem > 65536) {
-        static int granted = 0;
-        if (smem > granted) {
+        static bool granted = false;
+        if (!granted) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            granted = 160 * 1024;
+            granted = true;
         }
     }
     const int ncols = (C::TNT == 2) ? p.N / 2 : p.N;
@@ -701,25 +940,25 @@ inline hipError_t launch_skinny(const GemmP& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Burst depth from a register budget: accumulators + two slots of G k-steps of (B fragments + raw A units)
-// must stay well inside the 256 VGPRs a wave gets at <= 8 waves per workgroup.
+// Chunks in flight per wave from a register budget: accumulators + D x (B fragments + raw A units) must
+// stay inside the 256 VGPRs a wave gets at <= 8 waves per workgroup.
 template <int MT, bool PAIR, class LD>
-struct BurstDepth {
+struct ChunkDepth {
     static constexpr int TNT = PAIR ? 2 : 1;
-    static constexpr int fixed = MT * TNT * 16 + 40;
-    static constexpr int per_g = 2 * (TNT * 4 + MT * LD::kRawRegs);
-    static constexpr int G = (fixed + 4 * per_g <= 216) ? 4 : ((fixed + 2 * per_g <= 216) ? 2 : 1);
+    static constexpr int fixed = MT * TNT * 16 + 48 + MT * 4 * 6;
+    static constexpr int per_d = TNT * 16 + MT * 4 * LD::kRawRegs;
+    static constexpr int D = (fixed + 3 * per_d <= 230) ? 3 : ((fixed + 2 * per_d <= 230) ? 2 : 1);
 };
 
-// Skinny launch with the K-split chosen at run time: as many waves (<= 8) as give each >= 4 k-steps.
-template <int MT, bool PAIR, class LD, class EP>
+// Skinny launch, K split over as many waves (<= 8/WM) as keep >= 2 chunks per wave.
+template <int WM, int MT, bool PAIR, class LD, class EP>
 inline hipError_t launch_skinny_auto(const GemmP& p, hipStream_t s) {
-    constexpr int G = BurstDepth<MT, PAIR, LD>::G;
-    const int ksteps = p.Kp / 16;
-    if (ksteps >= 64) return launch_skinny<SkinnyCfg<MT, 8, PAIR, G>, LD, EP>(p, s);
-    if (ksteps >= 32) return launch_skinny<SkinnyCfg<MT, 4, PAIR, G>, LD, EP>(p, s);
-    if (ksteps >= 16) return launch_skinny<SkinnyCfg<MT, 2, PAIR, G>, LD, EP>(p, s);
-    return launch_skinny<SkinnyCfg<MT, 1, PAIR, G>, LD, EP>(p, s);
+    constexpr int D = ChunkDepth<MT, PAIR, LD>::D;
+    const int chunks = p.Kp / 64;
+    if constexpr (WM <= 1) if (chunks >= 16 && chunks % 8 == 0) return launch_skinny<SkinnyCfg<WM, 8, MT, PAIR, D>, LD, EP>(p, s);
+    if constexpr (WM <= 2) if (chunks >= 8 && chunks % 4 == 0) return launch_skinny<SkinnyCfg<WM, 4, MT, PAIR, D>, LD, EP>(p, s);
+    if constexpr (WM <= 4) if (chunks >= 4 && chunks % 2 == 0) return launch_skinny<SkinnyCfg<WM, 2, MT, PAIR, D>, LD, EP>(p, s);
+    return launch_skinny<SkinnyCfg<WM, 1, MT, PAIR, D>, LD, EP>(p, s);
 }
 
 }  // namespace hd

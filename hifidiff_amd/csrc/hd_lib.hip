@@ -56,7 +56,7 @@ struct ResConv { PackedW w; int cin, cout, k, stride, pad; };
 struct ResBlock { ResConv c1, c2, c3, ds; bool has_ds = false; };
 
 enum LdKind { LK_F32, LK_LN, LK_BF16, LK_BF16S, LK_CONV_F32, LK_CONV_F32G, LK_CONV_BF16 };
-enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16 };
+enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE };
 
 struct Op {
     std::string name;
@@ -326,22 +326,32 @@ hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
         switch (mode) {
             case 0: return launch_gemm<T128P, LD, EP>(p, s);
             case 1: return launch_gemm<T64P, LD, EP>(p, s);
-            case 2: return launch_skinny_auto<2, true, LD, EP>(p, s);
+            case 2: return launch_skinny_auto<1, 2, true, LD, EP>(p, s);
             case 4: return launch_gemm<T32WP, LD, EP>(p, s);
-            default: return launch_skinny_auto<1, true, LD, EP>(p, s);
+            default: return launch_skinny_auto<1, 1, true, LD, EP>(p, s);
         }
     } else {
         switch (mode) {
             case 0: return launch_gemm<T128, LD, EP>(p, s);
             case 1: return launch_gemm<T64, LD, EP>(p, s);
-            case 2: return launch_skinny_auto<2, false, LD, EP>(p, s);
+            case 2: return launch_skinny_auto<1, 2, false, LD, EP>(p, s);
             case 4: return launch_gemm<T32W, LD, EP>(p, s);
-            default: return launch_skinny_auto<1, false, LD, EP>(p, s);
+            default: return launch_skinny_auto<1, 1, false, LD, EP>(p, s);
         }
     }
 }
 
+// conv1 with the depthwise 3x3 + SimpleGate + pool fused: workgroup = whole faces (BM = max(32, hw) rows)
+hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
+    if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate>(p, s);
+    if (p.hw == 64) return launch_skinny_auto<2, 1, true, LdF32LN, EpDwGate>(p, s);
+    if (p.hw == 256) return launch_skinny_auto<8, 1, true, LdF32LN, EpDwGate>(p, s);
+    return hipErrorInvalidValue;
+}
+bool dwgate_ok(int hw) { return hw == 1 || hw == 4 || hw == 16 || hw == 64 || hw == 256; }
+
 hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStream_t s) {
+    if (lk == LK_LN && ek == EK_DWGATE) return dispatch_dwgate(p, s);
     if (lk == LK_LN && ek == EK_BIASF32) return launch_tile<LdF32LN, EpBiasF32, false>(p, mode, s);
     if (lk == LK_LN && ek == EK_GATE) return launch_tile<LdF32LN, EpGateBF16, true>(p, mode, s);
     if (lk == LK_F32 && ek == EK_BIASF32) return launch_tile<LdF32Plain, EpBiasF32, false>(p, mode, s);
@@ -379,11 +389,12 @@ GemmP base_gemm(const PackedW& w, int M) {
 }
 
 void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p, LdKind lk, EpKind ek) {
-    const int t128 = choose_mode(p, ek == EK_GATE);          // (kernel mode; name kept for the capture list)
+    int t128 = choose_mode(p, ek == EK_GATE || ek == EK_DWGATE);   // (kernel mode; name kept for the capture list)
+    if (t128 == 2 && lk == LK_CONV_F32G) t128 = 3;            // the gated gather needs the registers of a 32-row tile
     const bool film = (lk == LK_LN);
     size_t out_rows = (size_t)p.M * (ek == EK_PIXSHUF ? p.shuffle_r * p.shuffle_r : 1);
     Op op;
-    op.name = name; op.out = p.out; op.out_elems = out_rows * p.ldo; op.out_bf16 = (ek == EK_GATE || ek == EK_BIASBF16) ? 1 : 0;
+    op.name = name; op.out = p.out; op.out_elems = out_rows * p.ldo; op.out_bf16 = (ek == EK_GATE || ek == EK_BIASBF16 || ek == EK_DWGATE) ? 1 : 0;
     op.run = [c, p, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
                         if (film && p.film == nullptr) {          // denoiser FiLM rows live in the (re-allocatable) table
                             GemmP q = p;
@@ -412,22 +423,32 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         p.film_gain_off = bw.film_off + (2 * half + 1) * C;
         p.film_face_stride = 0; p.film_step_stride = 0; p.step_ptr = nullptr;
     };
-    {   // LN1 + FiLM -> conv1 (+bias) -> T1
+    static const bool no_fuse = getenv("HD_NO_DWFUSE") != nullptr;
+    if (dwgate_ok(HW) && !no_fuse) {
+        // LN1 + FiLM -> conv1 (+bias) -> depthwise 3x3 -> SimpleGate -> G, pooled mean: one launch
         GemmP p = base_gemm(bw.conv1, M);
         p.A = lv.X; p.lda = C; film_fields(p, 0);
         p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
-        p.out = lv.T1; p.ldo = 2 * C;
-        add_gemm(c, prog, bw.name + ".conv1", p, LK_LN, EK_BIASF32);
-    }
-    {   // depthwise 3x3 -> SimpleGate -> G, pooled mean
-        const float *T1 = lv.T1, *w = bw.dw_w, *b = bw.dw_b;
-        unsigned short* G = lv.G; float* pooled = lv.pooled;
-        const int H = lv.H, faces = M / HW;
-        prog.push_back({bw.name + ".conv2_gate_pool", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(dwconv_gate_pool_kernel, dim3(C / 32, faces), dim3(256), 0, s, T1, w, b, G, pooled, H, H, C);
-                            return hipGetLastError();
-                        }});
-        prog.back().out = G; prog.back().out_elems = (size_t)M * C; prog.back().out_bf16 = 1;
+        p.out = lv.G; p.ldo = C; p.dw_w = bw.dw_w; p.dw_b = bw.dw_b; p.pooled = lv.pooled; p.side = lv.H;
+        add_gemm(c, prog, bw.name + ".conv2_gate_pool", p, LK_LN, EK_DWGATE);
+    } else {
+        {   // LN1 + FiLM -> conv1 (+bias) -> T1
+            GemmP p = base_gemm(bw.conv1, M);
+            p.A = lv.X; p.lda = C; film_fields(p, 0);
+            p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
+            p.out = lv.T1; p.ldo = 2 * C;
+            add_gemm(c, prog, bw.name + ".conv1", p, LK_LN, EK_BIASF32);
+        }
+        {   // depthwise 3x3 -> SimpleGate -> G, pooled mean
+            const float *T1 = lv.T1, *w = bw.dw_w, *b = bw.dw_b;
+            unsigned short* G = lv.G; float* pooled = lv.pooled;
+            const int H = lv.H, faces = M / HW;
+            prog.push_back({bw.name + ".conv2_gate_pool", [=](hipStream_t s) -> hipError_t {
+                                hipLaunchKernelGGL(dwconv_gate_pool_kernel, dim3(C / 32, faces), dim3(256), 0, s, T1, w, b, G, pooled, H, H, C);
+                                return hipGetLastError();
+                            }});
+            prog.back().out = G; prog.back().out_elems = (size_t)M * C; prog.back().out_bf16 = 1;
+        }
     }
     {   // SCA 1x1 conv on the pooled vector
         GemmP p = base_gemm(bw.sca, M / HW);
