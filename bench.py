@@ -169,7 +169,8 @@ def main():
                                    % (B, L, L, L * 8, n_diff, a.kind.upper()),
                        "faces_per_gpu": B, "latent_res": L, "diffusion_steps": n_diff, "sampler": a.kind,
                        "parallelism": "batch-sharded x%d, no in-loop collective" % world,
-                       "launches_per_diffusion_step": Lh.hd_num_ops(model.engine.ctx, 0) + 1,
+                       "concurrent_chains": Lh.hd_num_chains(model.engine.ctx),
+                       "launches_per_diffusion_step": Lh.hd_num_ops(model.engine.ctx, 0) * Lh.hd_num_chains(model.engine.ctx) + 1,
                        "output_finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

@@ -21,7 +21,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
 
 EXPORTS = [
     "hd_create", "hd_destroy", "hd_last_error", "hd_load_weights", "hd_finalize_weights", "hd_prepare",
-    "hd_prepare_from_priors", "hd_fpg", "hd_idc", "hd_eps", "hd_sample", "hd_scheduler_step", "hd_num_ops",
+    "hd_prepare_from_priors", "hd_fpg", "hd_idc", "hd_eps", "hd_sample", "hd_scheduler_step", "hd_num_ops", "hd_num_chains",
     "hd_debug_limit_ops", "hd_debug_op_name", "hd_debug_read_op", "hd_debug_read", "hd_set_profiling", "hd_get_profile",
 ]
 
@@ -75,6 +75,7 @@ def lib():
     L.hd_sample.argtypes = [vp, vp, ctypes.POINTER(Schedule), vp, u64, vp]
     L.hd_scheduler_step.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float), vp, u64, i32, i64, vp]
     L.hd_num_ops.argtypes = [vp, i32]
+    L.hd_num_chains.argtypes = [vp]
     L.hd_debug_limit_ops.argtypes = [vp, i32, i32]
     L.hd_debug_op_name.argtypes = [vp, i32, i32]; L.hd_debug_op_name.restype = ctypes.c_char_p
     L.hd_debug_read_op.argtypes = [vp, i32, i32, vp, i64]; L.hd_debug_read_op.restype = i64

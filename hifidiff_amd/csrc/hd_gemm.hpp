@@ -51,6 +51,7 @@ struct GemmP {
     int lda;
     float a_scale;
     int hw;                       // rows per face
+    int face0;                    // first face of this launch inside the batch (per-face FiLM rows)
     const float* film;            // FiLM table (gain/bias rows)
     int film_face_stride, film_step_stride, film_gain_off, film_bias_off;
     const int* step_ptr;          // device step index (NULL -> 0)
@@ -244,7 +245,7 @@ struct LdF32LN {
         st.mu = s.x; st.rstd = s.y;
         st.gbl = (gb && p.film_face_stride == 0) ? gb : nullptr;      // LDS copy of the shared FiLM row
         const int step = p.step_ptr ? *p.step_ptr : 0;
-        const float* f = p.film + (size_t)step * p.film_step_stride + (size_t)(r / p.hw) * p.film_face_stride;
+        const float* f = p.film + (size_t)step * p.film_step_stride + (size_t)(p.face0 + r / p.hw) * p.film_face_stride;
         st.gain = f + p.film_gain_off;
         st.bias = f + p.film_bias_off;
     }
@@ -555,13 +556,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
 
     HD_STAMP(0);
     float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + C::GB_OFF) : nullptr;
-    LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
-
     typename LD::St st[C::UNITS];
     int u_ldsoff[C::UNITS];
     const int kq = tid & 7;
 #pragma unroll
-    for (int u = 0; u < C::UNITS; ++u) {
+    for (int u = 0; u < C::UNITS; ++u) {                   // row pointers (statistics filled in below)
         const int rl = (tid >> 3) + u * (C::THREADS / 8);
         u_ldsoff[u] = rl * LDS_ROW;
         LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
@@ -595,6 +594,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
 
     HD_FETCH_A(0);
     HD_LOAD_B(bcur, 0);
+    // the loads above do not depend on the LayerNorm statistics; merge them while the loads fly
+    LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
+    if (LD::kGainBiasLds) {
+#pragma unroll
+        for (int u = 0; u < C::UNITS; ++u) {
+            const int rl = (tid >> 3) + u * (C::THREADS / 8);
+            LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
+        }
+    }
     HD_STAMP(1);
     HD_WRITE_A(0, 0);
     __syncthreads();
@@ -756,10 +764,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     for (int d = 0; d < D; ++d) { HD_SK_LOAD_B(d, c0 + d); }
 
     float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + C::GB_OFF) : nullptr;
-    LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
     typename LD::St st[UN];
     int u_off[UN];
     const int kq = lane & 7;
+    // row pointers first (the statistics part of St is filled in after block_init): the A loads do not
+    // depend on the LayerNorm statistics, only finish() does
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int rw = (lane >> 3) + 8 * u;                      // row inside the wave's MT*32-row sub-tile
@@ -772,6 +781,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         LD::fetch(p, st[u], ((chunk) < c_end) ? (chunk) * BK : p.Kp, kq, aq[slot][u]);
 #pragma unroll
     for (int d = 0; d < D; ++d) { HD_SK_FETCH_A(d, c0 + d); }
+    LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
+    if (LD::kGainBiasLds) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int rl = wm * MT * 32 + (lane >> 3) + 8 * u;
+            LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
+        }
+    }
     HD_STAMP(1);
 
     char* sA = smem + wave * C::A_WAVE;

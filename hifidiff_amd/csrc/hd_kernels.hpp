@@ -305,8 +305,10 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 }
 
 // x0 = clamp((x - c0*eps)/c1, +-c2);  x <- c3*x0 + c4*x + c5*eps + c6*z      (hd_schedule in the C-ABI)
+// x/eps point at this chain's faces; elem0 / n_total place them inside the whole batch so that the noise
+// tensor and the Philox counters are indexed exactly as for an unsplit batch.
 __global__ void sched_step_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ coef,
-                                  const StepState* __restrict__ st, int n) {
+                                  const StepState* __restrict__ st, int n, int elem0, int n_total) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int step = st->step;
@@ -316,7 +318,7 @@ __global__ void sched_step_kernel(float* __restrict__ x, const float* __restrict
     x0 = fminf(fmaxf(x0, -c[2]), c[2]);
     float r = c[3] * x0 + c[4] * xv + c[5] * e;
     if (c[6] != 0.f) {
-        const float z = st->noise ? st->noise[(size_t)step * n + i] : philox_normal(st->seed, (unsigned)step, (unsigned)i);
+        const float z = st->noise ? st->noise[(size_t)step * n_total + elem0 + i] : philox_normal(st->seed, (unsigned)step, (unsigned)(elem0 + i));
         r += c[6] * z;
     }
     x[i] = r;

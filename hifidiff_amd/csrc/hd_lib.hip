@@ -70,6 +70,24 @@ struct Level { int C, H, M; float *X, *Y, *T1, *pooled, *S; unsigned short* G; f
 
 }  // namespace
 
+// One independently scheduled sub-batch: faces never interact inside the loop, so the batch is cut into
+// chains whose launch sequences run concurrently (forked branches of the captured graph) and overlap
+// each other's latency-bound phases.
+struct Chain {
+    int B = 0, face0 = 0, index = 0;
+    Level lv[5];
+    float *lat = nullptr, *eps = nullptr, *prior[5] = {}, *gate_c[5] = {}, *gate_s[5] = {}, *idc_term = nullptr;
+    float *id_emb = nullptr, *pool_tmp = nullptr, *mlp_tmp = nullptr, *sp_tmp = nullptr;
+    unsigned short* res_buf[4] = {};
+    uint4* face8 = nullptr;
+    std::vector<Op> program;                 // one denoiser evaluation (lat -> eps) of this chain's faces
+    std::vector<Op> prep_program;            // the most recent conditioning prologue
+    StepState* step_state = nullptr;         // device-resident loop state of this chain
+    hipStream_t stream = nullptr;            // the chain's own queue for the sampling loop
+    hipEvent_t done = nullptr;
+    hipGraphExec_t graph_exec = nullptr;     // program + scheduler update of this chain, replayed per step
+};
+
 static std::string g_create_error;
 
 struct hd_ctx {
@@ -95,11 +113,9 @@ struct hd_ctx {
 
     // batch-dependent workspace
     int B = 0;
-    Level lv[5];
-    float *lat = nullptr, *eps = nullptr, *prior[5] = {}, *gate_c[5] = {}, *gate_s[5] = {}, *idc_term = nullptr;
-    float *id_emb = nullptr, *pool_tmp = nullptr, *mlp_tmp = nullptr, *sp_tmp = nullptr;
-    unsigned short* res_buf[4] = {};
-    uint4* face8 = nullptr;
+    std::vector<Chain> chains;
+    Chain* ch = nullptr;                     // chain the builder functions currently work on
+    float *lat = nullptr, *eps = nullptr;    // [B,4,L,L] of the whole batch; chains own contiguous face ranges
     bool prepared = false;
 
     // FiLM / schedule
@@ -108,14 +124,12 @@ struct hd_ctx {
     int film_face_stride = 0, film_step_stride = 0;
     float* coef_dev = nullptr;
     int coef_cap = 0;
-    StepState* step_state = nullptr;
     int advance = 0;
+    hipEvent_t fork_ev = nullptr;
 
     // program
-    std::vector<Op> program;                 // one denoiser evaluation (lat -> eps)
-    std::vector<Op> prep_program;            // the most recent conditioning prologue
     int op_limit = -1, prep_limit = -1;
-    hipGraphExec_t graph_exec = nullptr;
+    bool graphs_valid = false;
     const float* graph_film = nullptr;
     int graph_B = 0;
 
@@ -395,13 +409,14 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
     size_t out_rows = (size_t)p.M * (ek == EK_PIXSHUF ? p.shuffle_r * p.shuffle_r : 1);
     Op op;
     op.name = name; op.out = p.out; op.out_elems = out_rows * p.ldo; op.out_bf16 = (ek == EK_GATE || ek == EK_BIASBF16 || ek == EK_DWGATE) ? 1 : 0;
-    op.run = [c, p, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
+    Chain* chp = c->ch;
+    op.run = [c, chp, p, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
                         if (film && p.film == nullptr) {          // denoiser FiLM rows live in the (re-allocatable) table
                             GemmP q = p;
                             q.film = c->film_table;
                             q.film_face_stride = c->film_face_stride;
                             q.film_step_stride = c->film_step_stride;
-                            q.step_ptr = &c->step_state->step;
+                            q.step_ptr = &chp->step_state->step;
                             return dispatch_gemm(q, lk, ek, t128, s);
                         }
                         return dispatch_gemm(p, lk, ek, t128, s);
@@ -417,7 +432,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
                    int* x_cnt) {
     const int C = bw.C, M = lv.M, HW = lv.H * lv.H;
     auto film_fields = [&](GemmP& p, int half) {
-        p.hw = HW;
+        p.hw = HW; p.face0 = c->ch->face0;
         p.film = static_film;                           // nullptr -> patched from the table at launch
         p.film_bias_off = bw.film_off + (2 * half) * C;
         p.film_gain_off = bw.film_off + (2 * half + 1) * C;
@@ -512,7 +527,7 @@ void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Hc
     p.A = in; p.lda = hw.C; p.Hin = H; p.Win = H; p.Cin = hw.C; p.Hout = H; p.Wout = H; p.stride = 1;
     if (hw.centre_only) { p.KH = 1; p.KW = 1; p.pad = 0; p.ntaps = 1; }
     else { p.KH = 3; p.KW = 3; p.pad = 1; p.ntaps = 9; }
-    p.gate_c = c->gate_c[idx]; p.gate_s = c->gate_s[idx]; p.add_src = add;
+    p.gate_c = c->ch->gate_c[idx]; p.gate_s = c->ch->gate_s[idx]; p.add_src = add;
     p.out = out; p.ldo = hw.C; p.act = 1;
     add_gemm(c, prog, name, p, LK_CONV_F32G, EK_BIASF32);
 }
@@ -529,58 +544,95 @@ int run_ops(hd_ctx* c, std::vector<Op>& prog, hipStream_t s, int limit = -1) {
 }
 
 // --------------------------------------------------------------------------------------- workspace
-int alloc_workspace(hd_ctx* c, int B) {
-    if (B == c->B) return HD_OK;
-    if (c->B != 0) HD_FAIL(c, HD_ERR_INVALID, "batch size change (%d -> %d) needs a new context", c->B, B);
-    const int L = c->L;
+int alloc_chain(hd_ctx* c, Chain& ch) {
+    const int L = c->L, B = ch.B;
+    const bool dbg = (ch.index == 0);                    // introspection reads chain 0
     int rc = 0;
     for (int l = 0; l < 5; ++l) {
-        Level& v = c->lv[l];
+        Level& v = ch.lv[l];
         v.C = WIDTH << l; v.H = L >> l; v.M = B * v.H * v.H;
         const size_t mc = (size_t)v.M * v.C;
         rc |= dev_alloc(c, &v.X, mc); rc |= dev_alloc(c, &v.Y, mc); rc |= dev_alloc(c, &v.T1, 2 * mc);
         rc |= dev_alloc(c, &v.G, mc); rc |= dev_alloc(c, &v.pooled, (size_t)B * v.C); rc |= dev_alloc(c, &v.S, (size_t)B * v.C);
         rc |= dev_alloc(c, &v.sx, (size_t)v.M * (v.C / 32)); rc |= dev_alloc(c, &v.sy, (size_t)v.M * (v.C / 32));
         const int pi = 4 - l;                            // prior index: coarsest first
-        rc |= dev_alloc(c, &c->prior[pi], mc); rc |= dev_alloc(c, &c->gate_c[pi], (size_t)B * v.C);
-        rc |= dev_alloc(c, &c->gate_s[pi], (size_t)v.M);
+        rc |= dev_alloc(c, &ch.prior[pi], mc); rc |= dev_alloc(c, &ch.gate_c[pi], (size_t)B * v.C);
+        rc |= dev_alloc(c, &ch.gate_s[pi], (size_t)v.M);
         if (rc) return rc;
-        const std::string s = std::to_string(l);
-        c->dbg["X" + s] = {v.X, {mc, 0}}; c->dbg["Y" + s] = {v.Y, {mc, 0}}; c->dbg["T1_" + s] = {v.T1, {2 * mc, 0}};
-        c->dbg["G" + s] = {v.G, {mc, 1}}; c->dbg["pooled" + s] = {v.pooled, {(size_t)B * v.C, 0}}; c->dbg["S" + s] = {v.S, {(size_t)B * v.C, 0}};
-        const std::string ps = std::to_string(pi);
-        c->dbg["prior" + ps] = {c->prior[pi], {mc, 0}}; c->dbg["wc" + ps] = {c->gate_c[pi], {(size_t)B * v.C, 0}};
-        c->dbg["ws" + ps] = {c->gate_s[pi], {(size_t)v.M, 0}};
+        if (dbg) {
+            const std::string s = std::to_string(l);
+            c->dbg["X" + s] = {v.X, {mc, 0}}; c->dbg["Y" + s] = {v.Y, {mc, 0}}; c->dbg["T1_" + s] = {v.T1, {2 * mc, 0}};
+            c->dbg["G" + s] = {v.G, {mc, 1}}; c->dbg["pooled" + s] = {v.pooled, {(size_t)B * v.C, 0}}; c->dbg["S" + s] = {v.S, {(size_t)B * v.C, 0}};
+            const std::string ps = std::to_string(pi);
+            c->dbg["prior" + ps] = {ch.prior[pi], {mc, 0}}; c->dbg["wc" + ps] = {ch.gate_c[pi], {(size_t)B * v.C, 0}};
+            c->dbg["ws" + ps] = {ch.gate_s[pi], {(size_t)v.M, 0}};
+        }
     }
-    const size_t nlat = (size_t)B * 4 * L * L;
-    rc |= dev_alloc(c, &c->lat, nlat); rc |= dev_alloc(c, &c->eps, nlat);
-    rc |= dev_alloc(c, &c->idc_term, (size_t)B * 2048 * c->S * c->S); rc |= dev_alloc(c, &c->id_emb, (size_t)B * 2048);
-    rc |= dev_alloc(c, &c->pool_tmp, (size_t)B * 2048); rc |= dev_alloc(c, &c->mlp_tmp, (size_t)B * 2048);
-    rc |= dev_alloc(c, &c->sp_tmp, (size_t)c->lv[0].M * 1024);      // max over levels of M_l * C_l/2 = B*L*L*64... generous
+    rc |= dev_alloc(c, &ch.idc_term, (size_t)B * 2048 * c->S * c->S); rc |= dev_alloc(c, &ch.id_emb, (size_t)B * 2048);
+    rc |= dev_alloc(c, &ch.pool_tmp, (size_t)B * 2048); rc |= dev_alloc(c, &ch.mlp_tmp, (size_t)B * 2048);
+    rc |= dev_alloc(c, &ch.sp_tmp, (size_t)ch.lv[0].M * 1024);       // >= max over levels of M_l * C_l / 2
     if (rc) return rc;
-    c->dbg["lat"] = {c->lat, {nlat, 0}}; c->dbg["eps"] = {c->eps, {nlat, 0}};
-    c->dbg["idc"] = {c->idc_term, {(size_t)B * 2048 * c->S * c->S, 0}}; c->dbg["id_emb"] = {c->id_emb, {(size_t)B * 2048, 0}};
+    if (dbg) { c->dbg["idc"] = {ch.idc_term, {(size_t)B * 2048 * c->S * c->S, 0}}; c->dbg["id_emb"] = {ch.id_emb, {(size_t)B * 2048, 0}}; }
     // ResNet activations (channels-last bf16); largest is conv1 output B x 64x64 x 64 == layer1 B x 32x32 x 256
     const size_t rmax = (size_t)B * 64 * 64 * 64;
-    for (int i = 0; i < 4; ++i) rc |= dev_alloc(c, &c->res_buf[i], rmax);
-    rc |= dev_alloc(c, &c->face8, (size_t)B * 128 * 128);
+    for (int i = 0; i < 4; ++i) rc |= dev_alloc(c, &ch.res_buf[i], rmax);
+    rc |= dev_alloc(c, &ch.face8, (size_t)B * 128 * 128);
+    rc |= dev_alloc(c, &ch.step_state, 1);
     if (rc) return rc;
+    HIPCHECK(c, hipMemset(ch.step_state, 0, sizeof(StepState)));
+    HIPCHECK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
+    HIPCHECK(c, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
+    return HD_OK;
+}
+
+int build_denoiser_program(hd_ctx* c);
+
+// Cut the batch into chains.  Default: 2 chains once each still holds >= 16 faces (the GEMM tiles are 32
+// rows, so smaller chains waste MFMA rows); HD_CHAINS overrides.
+int alloc_workspace(hd_ctx* c, int B) {
+    if (B == c->B) return HD_OK;
+    if (c->B != 0) HD_FAIL(c, HD_ERR_INVALID, "batch size change (%d -> %d) needs a new context", c->B, B);
+    int n = (B >= 32) ? 2 : 1;
+    if (const char* e = getenv("HD_CHAINS")) n = atoi(e);
+    if (n < 1) n = 1;
+    if (n > 8) n = 8;
+    while (n > 1 && B % n != 0) --n;
+    const size_t per_face = (size_t)4 * c->L * c->L;
+    int rc = 0;
+    rc |= dev_alloc(c, &c->lat, (size_t)B * per_face); rc |= dev_alloc(c, &c->eps, (size_t)B * per_face);
+    if (rc) return rc;
+    c->dbg["lat"] = {c->lat, {(size_t)B * per_face, 0}}; c->dbg["eps"] = {c->eps, {(size_t)B * per_face, 0}};
+    c->chains.resize(n);
+    for (int i = 0; i < n; ++i) {
+        Chain& ch = c->chains[i];
+        ch.index = i; ch.B = B / n; ch.face0 = i * (B / n);
+        ch.lat = c->lat + (size_t)ch.face0 * per_face; ch.eps = c->eps + (size_t)ch.face0 * per_face;
+        rc = alloc_chain(c, ch);
+        if (rc) return rc;
+    }
     c->B = B;
+    for (auto& ch : c->chains) {
+        c->ch = &ch;
+        rc = build_denoiser_program(c);
+        if (rc) return rc;
+    }
+    c->ch = &c->chains[0];
     return HD_OK;
 }
 
 // ----------------------------------------------------------------------------- program construction
 int build_denoiser_program(hd_ctx* c) {
-    std::vector<Op>& prog = c->program;
+    std::vector<Op>& prog = c->ch->program;
     prog.clear();
-    const int B = c->B, L = c->L;
+    const int B = c->ch->B, L = c->L;
+    Chain* chp = c->ch;
     const RawTensor *iw = find_raw(c, "denoiser.intro.weight"), *ib = find_raw(c, "denoiser.intro.bias");
     const RawTensor *ew = find_raw(c, "denoiser.ending.weight"), *eb = find_raw(c, "denoiser.ending.bias");
     {
-        const float *lat = c->lat, *w = iw->dev, *b = ib->dev; float* out = c->lv[0].X; float2* sx = c->lv[0].sx;
-        const int M = c->lv[0].M;
+        const float *lat = c->ch->lat, *w = iw->dev, *b = ib->dev; float* out = c->ch->lv[0].X; float2* sx = c->ch->lv[0].sx;
+        const int M = c->ch->lv[0].M;
         prog.push_back({"intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, lat, w, b, out, sx, B, L, c->step_state, c->advance);
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, lat, w, b, out, sx, B, L, chp->step_state, c->advance);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
@@ -589,16 +641,16 @@ int build_denoiser_program(hd_ctx* c) {
     int bi = 0;
     int np = 1, cnt = WIDTH;                            // intro emits one (mean, M2) partial per row
     for (int l = 0; l < 4; ++l) {
-        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->lv[l], nullptr, &np, &cnt);
-        add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->lv[l], c->lv[l + 1]);
-        np = c->lv[l + 1].C / 32; cnt = 32;
+        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[l], nullptr, &np, &cnt);
+        add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
+        np = c->ch->lv[l + 1].C / 32; cnt = 32;
     }
-    for (int j = 0; j < 8; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->lv[4], nullptr, &np, &cnt);
+    for (int j = 0; j < 8; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[4], nullptr, &np, &cnt);
     // x + idc_conv(id) -> HCA0 (model.py:245-247); the add is folded into the HCA loader
-    add_hca(c, prog, "hcas.0", c->hca[0], 0, c->lv[4].X, c->idc_term, c->lv[4].Y, c->lv[4].M, c->lv[4].H);
+    add_hca(c, prog, "hcas.0", c->hca[0], 0, c->ch->lv[4].X, c->ch->idc_term, c->ch->lv[4].Y, c->ch->lv[4].M, c->ch->lv[4].H);
     for (int i = 0; i < 4; ++i) {
         const int l = 3 - i;
-        const Level &hi = c->lv[l + 1], &lo = c->lv[l];
+        const Level &hi = c->ch->lv[l + 1], &lo = c->ch->lv[l];
         add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], hi.Y, hi.M, hi.H, hi.C, lo.X, lo.X, 2);
         add_row_stats(prog, "ups." + std::to_string(i) + ".row_stats", lo.X, lo.sx, lo.M, lo.C);
         np = 1; cnt = lo.C;
@@ -606,8 +658,8 @@ int build_denoiser_program(hd_ctx* c) {
         add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], i + 1, lo.X, nullptr, lo.Y, lo.M, lo.H);
     }
     {
-        const float *X = c->lv[0].Y, *w = ew->dev, *b = eb->dev; float* eps = c->eps;
-        const int M = c->lv[0].M;
+        const float *X = c->ch->lv[0].Y, *w = ew->dev, *b = eb->dev; float* eps = c->ch->eps;
+        const int M = c->ch->lv[0].M;
         prog.push_back({"ending", [=](hipStream_t s) -> hipError_t {
                             hipLaunchKernelGGL(ending_conv_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, w, b, eps, B, L);
                             return hipGetLastError();
@@ -619,11 +671,11 @@ int build_denoiser_program(hd_ctx* c) {
 
 // HCA gates from prior maps (hca.py:33-48): w_c -> gate_c[i], w_s -> gate_s[i]
 void add_gates(hd_ctx* c, std::vector<Op>& prog, int i) {
-    const Level& lv = c->lv[4 - i];
+    const Level& lv = c->ch->lv[4 - i];
     const HcaW& hw = c->hca[i];
-    const int C = hw.C, HW = lv.H * lv.H, B = c->B, M = lv.M;
-    const float* prior = c->prior[i];
-    float *pool = c->pool_tmp, *mlp = c->mlp_tmp, *sp = c->sp_tmp, *gc = c->gate_c[i], *gs = c->gate_s[i];
+    const int C = hw.C, HW = lv.H * lv.H, B = c->ch->B, M = lv.M;
+    const float* prior = c->ch->prior[i];
+    float *pool = c->ch->pool_tmp, *mlp = c->ch->mlp_tmp, *sp = c->ch->sp_tmp, *gc = c->ch->gate_c[i], *gs = c->ch->gate_s[i];
     const std::string n = "hcas." + std::to_string(i);
     prog.push_back({n + ".pool", [=](hipStream_t s) -> hipError_t {
                         hipLaunchKernelGGL(pool_avgmax_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, prior, pool, HW, C);
@@ -644,18 +696,19 @@ void add_gates(hd_ctx* c, std::vector<Op>& prog, int i) {
 }
 
 void add_idc_term(hd_ctx* c, std::vector<Op>& prog) {
-    GemmP p = base_gemm(c->idc_conv, c->B);
-    p.A = c->id_emb; p.lda = 2048; p.out = c->idc_term; p.ldo = c->idc_conv.N;
+    GemmP p = base_gemm(c->idc_conv, c->ch->B);
+    p.A = c->ch->id_emb; p.lda = 2048; p.out = c->ch->idc_term; p.ldo = c->idc_conv.N;
     add_gemm(c, prog, "idc_conv", p, LK_F32, EK_BIASF32);
 }
 
 void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
-    const int B = c->B, L = c->L;
+    const int B = c->ch->B, L = c->L;
     const RawTensor *iw = find_raw(c, "fpg.intro.weight"), *ib = find_raw(c, "fpg.intro.bias");
     {
-        const float *w = iw->dev, *b = ib->dev; float* out = c->lv[0].X; const int M = c->lv[0].M; float2* sx = c->lv[0].sx;
+        const float *w = iw->dev, *b = ib->dev; float* out = c->ch->lv[0].X; const int M = c->ch->lv[0].M; float2* sx = c->ch->lv[0].sx;
+        Chain* chp = c->ch;
         prog.push_back({"fpg.intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, cr_latent_dev, w, b, out, sx, B, L, c->step_state, 0);
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, cr_latent_dev, w, b, out, sx, B, L, chp->step_state, 0);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
@@ -664,18 +717,18 @@ void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
     int bi = 0;
     int np = 1, cnt = WIDTH;
     for (int l = 0; l < 4; ++l) {
-        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->fpg_blocks[bi++], c->lv[l], c->fpg_ln_pack, &np, &cnt);
-        add_down(c, prog, "fpg.downs." + std::to_string(l), c->fpg_down[l], c->lv[l], c->lv[l + 1]);
-        np = c->lv[l + 1].C / 32; cnt = 32;
+        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->fpg_blocks[bi++], c->ch->lv[l], c->fpg_ln_pack, &np, &cnt);
+        add_down(c, prog, "fpg.downs." + std::to_string(l), c->fpg_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
+        np = c->ch->lv[l + 1].C / 32; cnt = 32;
     }
     // convs[0]: 1x1, PixelShuffle(1) == identity -> prior0; then 4x (1x1, PixelShuffle(2), + enc skip)
-    add_up(c, prog, "fpg.convs.0", c->fpg_convs[0], c->lv[4].X, c->lv[4].M, c->lv[4].H, c->lv[4].C, c->prior[0], nullptr, 1);
+    add_up(c, prog, "fpg.convs.0", c->fpg_convs[0], c->ch->lv[4].X, c->ch->lv[4].M, c->ch->lv[4].H, c->ch->lv[4].C, c->ch->prior[0], nullptr, 1);
     for (int i = 1; i < 5; ++i) {
-        const Level &hi = c->lv[5 - i], &lo = c->lv[4 - i];
+        const Level &hi = c->ch->lv[5 - i], &lo = c->ch->lv[4 - i];
         // out = shuffled + skip: write into prior[i] with the encoder output as the additive source
         GemmP p = base_gemm(c->fpg_convs[i], hi.M);
-        p.A = c->prior[i - 1]; p.lda = hi.C; p.Hin = hi.H; p.Win = hi.H; p.shuffle_r = 2;
-        p.out = c->prior[i]; p.ldo = lo.C; p.resid = lo.X; p.bias = nullptr;
+        p.A = c->ch->prior[i - 1]; p.lda = hi.C; p.Hin = hi.H; p.Win = hi.H; p.shuffle_r = 2;
+        p.out = c->ch->prior[i]; p.ldo = lo.C; p.resid = lo.X; p.bias = nullptr;
         add_gemm(c, prog, "fpg.convs." + std::to_string(i), p, LK_F32, EK_PIXSHUF);
     }
 }
@@ -683,7 +736,7 @@ void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
 void add_resconv(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const ResConv& rc, const unsigned short* in, int Hin,
                  unsigned short* out, const unsigned short* resid, bool relu) {
     const int Hout = (Hin + 2 * rc.pad - rc.k) / rc.stride + 1;
-    GemmP p = base_gemm(rc.w, c->B * Hout * Hout);
+    GemmP p = base_gemm(rc.w, c->ch->B * Hout * Hout);
     p.A = in; p.out = out; p.ldo = rc.cout; p.resid = resid; p.ldr = rc.cout; p.act = relu ? 1 : 0;
     if (rc.k == 1 && rc.stride == 1) {
         p.lda = rc.cin;
@@ -698,17 +751,17 @@ void add_resconv(hd_ctx* c, std::vector<Op>& prog, const std::string& name, cons
 
 // ResNet-50 trunk (idc/model.py:122-135) on cr_face -> id_emb [B][2048]
 void add_resnet(hd_ctx* c, std::vector<Op>& prog, const float* cr_face_dev) {
-    const int B = c->B;
+    const int B = c->ch->B;
     {
-        uint4* f8 = c->face8; const size_t npix = (size_t)B * 128 * 128;
+        uint4* f8 = c->ch->face8; const size_t npix = (size_t)B * 128 * 128;
         prog.push_back({"idc.input", [=](hipStream_t s) -> hipError_t {
                             hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, cr_face_dev, f8, 128 * 128, npix);
                             return hipGetLastError();
                         }});
         prog.back().out = f8; prog.back().out_elems = npix * 8; prog.back().out_bf16 = 1;
     }
-    unsigned short *b0 = c->res_buf[0], *b1 = c->res_buf[1], *b2 = c->res_buf[2], *b3 = c->res_buf[3];
-    add_resconv(c, prog, "idc.conv1", c->res_conv1, reinterpret_cast<const unsigned short*>(c->face8), 128, b0, nullptr, true);
+    unsigned short *b0 = c->ch->res_buf[0], *b1 = c->ch->res_buf[1], *b2 = c->ch->res_buf[2], *b3 = c->ch->res_buf[3];
+    add_resconv(c, prog, "idc.conv1", c->res_conv1, reinterpret_cast<const unsigned short*>(c->ch->face8), 128, b0, nullptr, true);
     {
         const size_t total = (size_t)B * 32 * 32 * 64;
         prog.push_back({"idc.max_pool", [=](hipStream_t s) -> hipError_t {
@@ -735,7 +788,7 @@ void add_resnet(hd_ctx* c, std::vector<Op>& prog, const float* cr_face_dev) {
             H = Hout;
         }
     {
-        float* emb = c->id_emb; const unsigned short* xin = x; const int HW = H * H;
+        float* emb = c->ch->id_emb; const unsigned short* xin = x; const int HW = H * H;
         prog.push_back({"idc.avgpool", [=](hipStream_t s) -> hipError_t {
                             hipLaunchKernelGGL(avgpool_bf16_kernel, dim3(2048 / 256, B), dim3(256), 0, s, xin, emb, HW, 2048);
                             return hipGetLastError();
@@ -796,15 +849,14 @@ int hd_create(hd_ctx** out, int latent_res, int device) {
     }
     hd_ctx* c = new hd_ctx();
     c->L = latent_res; c->device = device; c->S = latent_res / 16;
-    int rc = dev_alloc(c, &c->step_state, 1);
-    if (!rc) rc = dev_alloc(c, &c->freq_dev, 64);
+    int rc = dev_alloc(c, &c->freq_dev, 64);
     if (rc) { g_create_error = c->err; hd_destroy(c); return rc; }
-    (void)hipMemset(c->step_state, 0, sizeof(StepState));
     float freq[64];
     const float e = (float)(-(std::log(10000.0) / 63.0));       // model.py:25: python double, then fp32 tensor math
     for (int k = 0; k < 64; ++k) freq[k] = expf((float)k * e);
     (void)hipMemcpy(c->freq_dev, freq, sizeof(freq), hipMemcpyHostToDevice);
     (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
+    (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
     *out = c;
     return HD_OK;
 }
@@ -813,7 +865,12 @@ void hd_destroy(hd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    for (auto& ch : c->chains) {
+        if (ch.graph_exec) (void)hipGraphExecDestroy(ch.graph_exec);
+        if (ch.stream) (void)hipStreamDestroy(ch.stream);
+        if (ch.done) (void)hipEventDestroy(ch.done);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto& kv : c->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
@@ -1026,11 +1083,7 @@ static int prepare_common(hd_ctx* c, int batch) {
     if (rc) return rc;
     if (batch <= 0 || batch > 4096) HD_FAIL(c, HD_ERR_INVALID, "batch must be in [1, 4096]");
     HIPCHECK(c, hipSetDevice(c->device));
-    const bool fresh = (c->B == 0);
-    rc = alloc_workspace(c, batch);
-    if (rc) return rc;
-    if (fresh) rc = build_denoiser_program(c);
-    return rc;
+    return alloc_workspace(c, batch);
 }
 
 int hd_prepare(hd_ctx* c, int batch, const float* cr_latent, const float* cr_face, const float* id_emb, void* stream) {
@@ -1038,14 +1091,20 @@ int hd_prepare(hd_ctx* c, int batch, const float* cr_latent, const float* cr_fac
     if (rc) return rc;
     if (!cr_latent || (!cr_face == !id_emb)) HD_FAIL(c, HD_ERR_INVALID, "need cr_latent and exactly one of cr_face / id_emb");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    std::vector<Op> prog;
-    add_fpg(c, prog, cr_latent);
-    if (cr_face) add_resnet(c, prog, cr_face);
-    else HIPCHECK(c, hipMemcpyAsync(c->id_emb, id_emb, (size_t)batch * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    for (int i = 0; i < 5; ++i) add_gates(c, prog, i);
-    add_idc_term(c, prog);
-    rc = run_ops(c, prog, s, c->prep_limit);
-    c->prep_program.swap(prog);
+    const size_t lat_face = (size_t)4 * c->L * c->L;
+    for (auto& ch : c->chains) {
+        c->ch = &ch;
+        std::vector<Op> prog;
+        add_fpg(c, prog, cr_latent + ch.face0 * lat_face);
+        if (cr_face) add_resnet(c, prog, cr_face + (size_t)ch.face0 * 3 * 128 * 128);
+        else HIPCHECK(c, hipMemcpyAsync(ch.id_emb, id_emb + (size_t)ch.face0 * 2048, (size_t)ch.B * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        for (int i = 0; i < 5; ++i) add_gates(c, prog, i);
+        add_idc_term(c, prog);
+        rc = run_ops(c, prog, s, ch.index == 0 ? c->prep_limit : -1);
+        ch.prep_program.swap(prog);
+        if (rc) break;
+    }
+    c->ch = &c->chains[0];
     if (rc) return rc;
     c->prepared = true;
     return HD_OK;
@@ -1055,19 +1114,25 @@ int hd_prepare_from_priors(hd_ctx* c, int batch, const float* const priors[5], c
     int rc = prepare_common(c, batch);
     if (rc) return rc;
     if (!priors || !id_emb) HD_FAIL(c, HD_ERR_INVALID, "priors and id_emb are required");
+    for (int i = 0; i < 5; ++i) if (!priors[i]) HD_FAIL(c, HD_ERR_INVALID, "prior %d is NULL", i);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    for (int i = 0; i < 5; ++i) {
-        if (!priors[i]) HD_FAIL(c, HD_ERR_INVALID, "prior %d is NULL", i);
-        const Level& lv = c->lv[4 - i];
-        const size_t total = (size_t)lv.M * lv.C;
-        hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, priors[i], c->prior[i], lv.C, lv.H * lv.H, total);
+    for (auto& ch : c->chains) {
+        c->ch = &ch;
+        for (int i = 0; i < 5; ++i) {
+            const Level& lv = ch.lv[4 - i];
+            const size_t total = (size_t)lv.M * lv.C;          // per chain; faces are contiguous in NCHW too
+            hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                               priors[i] + (size_t)ch.face0 * lv.C * lv.H * lv.H, ch.prior[i], lv.C, lv.H * lv.H, total);
+        }
+        HIPCHECK(c, hipGetLastError());
+        HIPCHECK(c, hipMemcpyAsync(ch.id_emb, id_emb + (size_t)ch.face0 * 2048, (size_t)ch.B * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        std::vector<Op> prog;
+        for (int i = 0; i < 5; ++i) add_gates(c, prog, i);
+        add_idc_term(c, prog);
+        rc = run_ops(c, prog, s);
+        if (rc) break;
     }
-    HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(c->id_emb, id_emb, (size_t)batch * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    std::vector<Op> prog;
-    for (int i = 0; i < 5; ++i) add_gates(c, prog, i);
-    add_idc_term(c, prog);
-    rc = run_ops(c, prog, s);
+    c->ch = &c->chains[0];
     if (rc) return rc;
     c->prepared = true;
     return HD_OK;
@@ -1078,16 +1143,23 @@ int hd_fpg(hd_ctx* c, int batch, const float* cr_latent, float* const priors_out
     if (rc) return rc;
     if (!cr_latent || !priors_out) HD_FAIL(c, HD_ERR_INVALID, "hd_fpg: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    std::vector<Op> prog;
-    add_fpg(c, prog, cr_latent);
-    rc = run_ops(c, prog, s);
-    if (rc) return rc;
-    for (int i = 0; i < 5; ++i) {
-        if (!priors_out[i]) continue;
-        const Level& lv = c->lv[4 - i];
-        const size_t total = (size_t)lv.M * lv.C;
-        hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->prior[i], priors_out[i], lv.C, lv.H * lv.H, total);
+    const size_t lat_face = (size_t)4 * c->L * c->L;
+    for (auto& ch : c->chains) {
+        c->ch = &ch;
+        std::vector<Op> prog;
+        add_fpg(c, prog, cr_latent + ch.face0 * lat_face);
+        rc = run_ops(c, prog, s);
+        if (rc) break;
+        for (int i = 0; i < 5; ++i) {
+            if (!priors_out[i]) continue;
+            const Level& lv = ch.lv[4 - i];
+            const size_t total = (size_t)lv.M * lv.C;
+            hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ch.prior[i],
+                               priors_out[i] + (size_t)ch.face0 * lv.C * lv.H * lv.H, lv.C, lv.H * lv.H, total);
+        }
     }
+    c->ch = &c->chains[0];
+    if (rc) return rc;
     HIPCHECK(c, hipGetLastError());
     return HD_OK;
 }
@@ -1097,12 +1169,16 @@ int hd_idc(hd_ctx* c, int batch, const float* cr_face, float* id_emb_out, void* 
     if (rc) return rc;
     if (!cr_face || !id_emb_out) HD_FAIL(c, HD_ERR_INVALID, "hd_idc: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    std::vector<Op> prog;
-    add_resnet(c, prog, cr_face);
-    rc = run_ops(c, prog, s);
-    if (rc) return rc;
-    HIPCHECK(c, hipMemcpyAsync(id_emb_out, c->id_emb, (size_t)batch * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return HD_OK;
+    for (auto& ch : c->chains) {
+        c->ch = &ch;
+        std::vector<Op> prog;
+        add_resnet(c, prog, cr_face + (size_t)ch.face0 * 3 * 128 * 128);
+        rc = run_ops(c, prog, s);
+        if (rc) break;
+        HIPCHECK(c, hipMemcpyAsync(id_emb_out + (size_t)ch.face0 * 2048, ch.id_emb, (size_t)ch.B * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    c->ch = &c->chains[0];
+    return rc;
 }
 
 int hd_scheduler_step(float* x_inout, const float* eps, const float* coef7, const float* noise, uint64_t seed, int step,
@@ -1125,14 +1201,16 @@ int hd_eps(hd_ctx* c, const float* x, const float* timesteps, int n_t, float* ep
     if (rc) return rc;
     const size_t nlat = (size_t)c->B * 4 * c->L * c->L;
     HIPCHECK(c, hipMemcpyAsync(c->lat, x, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHECK(c, hipMemsetAsync(c->step_state, 0, sizeof(StepState), s));
+    for (auto& ch : c->chains) HIPCHECK(c, hipMemsetAsync(ch.step_state, 0, sizeof(StepState), s));
     rc = compute_film(c, timesteps, n_t, s);
     if (rc) return rc;
     c->film_step_stride = 0;
     c->film_face_stride = (n_t == 1) ? 0 : c->film_total;
     c->advance = 0;
-    rc = run_ops(c, c->program, s, c->op_limit);
-    if (rc) return rc;
+    for (auto& ch : c->chains) {
+        rc = run_ops(c, ch.program, s, ch.index == 0 ? c->op_limit : -1);
+        if (rc) return rc;
+    }
     HIPCHECK(c, hipMemcpyAsync(eps_out, c->eps, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     return HD_OK;
 }
@@ -1151,52 +1229,68 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
         rc = dev_alloc(c, &c->coef_dev, (size_t)n * 7);
         if (rc) return rc;
         c->coef_cap = n;
-        if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+        c->graphs_valid = false;
     }
-    const size_t nlat = (size_t)c->B * 4 * c->L * c->L;
-    // schedule, FiLM table for every step, loop state (step = -1: the intro kernel pre-increments)
+    const size_t per_face = (size_t)4 * c->L * c->L;
+    const size_t nlat = (size_t)c->B * per_face;
+    // schedule, FiLM table for every step, loop state (step = -1: each chain's intro kernel pre-increments)
     HIPCHECK(c, hipMemcpyAsync(c->coef_dev, sched->coef, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHECK(c, hipMemcpyAsync(c->t_dev, sched->timesteps, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
     StepState st{};
     st.step = -1; st.noise = noise; st.seed = seed;
-    HIPCHECK(c, hipMemcpyAsync(c->step_state, &st, sizeof(st), hipMemcpyHostToDevice, s));
-    HIPCHECK(c, hipStreamSynchronize(s));                 // the three host buffers above are caller/stack memory
+    for (auto& ch : c->chains) HIPCHECK(c, hipMemcpyAsync(ch.step_state, &st, sizeof(st), hipMemcpyHostToDevice, s));
+    HIPCHECK(c, hipStreamSynchronize(s));                 // the host buffers above are caller/stack memory
     HIPCHECK(c, hipMemcpyAsync(c->lat, x_inout, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     rc = compute_film(c, c->t_dev, n, s);
     if (rc) return rc;
     c->film_step_stride = c->film_total;
     c->film_face_stride = 0;
     c->advance = 1;
-    if (!c->graph_exec || c->graph_film != c->film_table || c->graph_B != c->B) {
-        if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-        hipStream_t cs;
-        HIPCHECK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            rc = run_ops(c, c->program, cs, -1);
-            if (rc == HD_OK) {
-                hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((nlat + 255) / 256)), dim3(256), 0, cs, c->lat, c->eps, c->coef_dev, c->step_state, (int)nlat);
+    if (!c->graphs_valid || c->graph_film != c->film_table || c->graph_B != c->B) {
+        // One graph per chain: its launch program + its scheduler update.  Faces never interact, so the
+        // chains are independent over the whole loop and each graph is replayed on the chain's own stream.
+        for (auto& ch : c->chains) {
+            if (ch.graph_exec) { (void)hipGraphExecDestroy(ch.graph_exec); ch.graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(ch.stream, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                for (size_t k = 0; k < ch.program.size() && e == hipSuccess; ++k) e = ch.program[k].run(ch.stream);
+                if (e == hipSuccess) {
+                    const int nel = (int)(ch.B * per_face);
+                    hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ch.stream, ch.lat, ch.eps, c->coef_dev,
+                                       ch.step_state, nel, (int)(ch.face0 * per_face), (int)nlat);
+                    e = hipGetLastError();
+                }
+                hipError_t e2 = hipStreamEndCapture(ch.stream, &graph);
+                if (e == hipSuccess) e = e2;
             }
-            hipError_t e2 = hipStreamEndCapture(cs, &graph);
-            if (rc == HD_OK && e2 != hipSuccess) { e = e2; }
+            if (e == hipSuccess) e = hipGraphInstantiate(&ch.graph_exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) HD_FAIL(c, HD_ERR_HIP, "graph capture/instantiate failed: %s", hipGetErrorString(e));
         }
-        if (rc == HD_OK && e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipStreamDestroy(cs);
-        if (rc) return rc;
-        if (e != hipSuccess) HD_FAIL(c, HD_ERR_HIP, "graph capture/instantiate failed: %s", hipGetErrorString(e));
-        c->graph_film = c->film_table; c->graph_B = c->B;
+        c->graphs_valid = true; c->graph_film = c->film_table; c->graph_B = c->B;
     }
     if (c->profiling) HIPCHECK(c, hipEventRecord(c->ev0, s));
-    for (int i = 0; i < n; ++i) HIPCHECK(c, hipGraphLaunch(c->graph_exec, s));
+    HIPCHECK(c, hipEventRecord(c->fork_ev, s));
+    for (auto& ch : c->chains) HIPCHECK(c, hipStreamWaitEvent(ch.stream, c->fork_ev, 0));
+    for (int i = 0; i < n; ++i)
+        for (auto& ch : c->chains) HIPCHECK(c, hipGraphLaunch(ch.graph_exec, ch.stream));
+    for (auto& ch : c->chains) {
+        HIPCHECK(c, hipEventRecord(ch.done, ch.stream));
+        HIPCHECK(c, hipStreamWaitEvent(s, ch.done, 0));
+    }
     if (c->profiling) { HIPCHECK(c, hipEventRecord(c->ev1, s)); c->last_steps = n; }
     HIPCHECK(c, hipMemcpyAsync(x_inout, c->lat, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     return HD_OK;
 }
 
-static std::vector<Op>* which_program(hd_ctx* c, int which) { return which == 0 ? &c->program : &c->prep_program; }
+static std::vector<Op>* which_program(hd_ctx* c, int which) {
+    static std::vector<Op> empty;
+    if (c->chains.empty()) return &empty;
+    return which == 0 ? &c->chains[0].program : &c->chains[0].prep_program;
+}
 int hd_num_ops(hd_ctx* c, int which) { return c ? (int)which_program(c, which)->size() : 0; }
+int hd_num_chains(hd_ctx* c) { return c ? (int)c->chains.size() : 0; }
 int hd_debug_limit_ops(hd_ctx* c, int which, int n) {
     if (!c) return HD_ERR_INVALID;
     (which == 0 ? c->op_limit : c->prep_limit) = n;

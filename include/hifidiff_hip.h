@@ -107,7 +107,8 @@ int hd_scheduler_step(float* x_inout, const float* eps, const float* coef7, cons
 /* Introspection for tests and profiling (not on the hot path; reads synchronise the device).
  * `which` selects the launch program: 0 = one denoiser evaluation (hd_eps / one hd_sample step),
  * 1 = the most recent hd_prepare prologue. */
-int hd_num_ops(hd_ctx* ctx, int which);                    /* kernel launches in the program          */
+int hd_num_ops(hd_ctx* ctx, int which);                    /* kernel launches in the program (one chain) */
+int hd_num_chains(hd_ctx* ctx);                            /* concurrently scheduled sub-batches       */
 int hd_debug_limit_ops(hd_ctx* ctx, int which, int n_ops); /* run only the first n ops (<0: all)      */
 const char* hd_debug_op_name(hd_ctx* ctx, int which, int i);
 /* copy the output buffer of op i to the host as fp32; host_out NULL -> just return the element count */
