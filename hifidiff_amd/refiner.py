@@ -297,7 +297,12 @@ class FacialRefiner(nn.Module):
         """Once-per-batch conditioning (FPG, IDC, HCA gates, idc_conv)."""
         e = self._engine
         e.ensure(cr_latent.device)
-        key = (cr_face.data_ptr(), cr_face._version, cr_latent.data_ptr(), cr_latent._version, tuple(cr_latent.shape))
+        B, L = cr_latent.shape[0], e.latent_res
+        if tuple(cr_latent.shape) != (B, 4, L, L) or tuple(cr_face.shape) != (B, 3, 128, 128):
+            raise RuntimeError("expected cr_latent (B,4,%d,%d) and cr_face (B,3,128,128), got %s and %s"
+                               % (L, L, tuple(cr_latent.shape), tuple(cr_face.shape)))
+        key = (cr_face.data_ptr(), cr_face._version, tuple(cr_face.shape), tuple(cr_face.stride()),
+               cr_latent.data_ptr(), cr_latent._version, tuple(cr_latent.shape), tuple(cr_latent.stride()))
         if self.cache_conditioning and e.cond_key == key and e.batch == cr_latent.shape[0]:
             return
         e.prepare(cr_latent, cr_face=cr_face)

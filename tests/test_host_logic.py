@@ -1,0 +1,110 @@
+"""CPU tests of the host side: C-ABI surface, parameter manifest, synthetic generator, scheduler tables,
+batch sharding over torch.distributed (gloo, world_size 2).  No GPU compute is called."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from hifidiff_amd import _lib, arch, distributed, schedulers, synth
+from oracle import hifidiff_oracle as O
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "hifidiff_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)                 # comments mention hd_schedule(...) etc.
+    declared = set(re.findall(r"\b(hd_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hifidiff_amd.refiner import FacialRefiner
+    m = FacialRefiner(16)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 16, 16), 0, torch.zeros(1, 3, 128, 128), torch.zeros(1, 4, 16, 16))
+    ctx = ctypes.c_void_p()
+    rc = _lib.lib().hd_create(ctypes.byref(ctx), 16, 0)
+    assert rc < 0 and b"HIP" in _lib.lib().hd_last_error(None) or b"device" in _lib.lib().hd_last_error(None)
+
+
+def test_manifest_counts():
+    man = arch.refiner_manifest(16)
+    assert len(man) == 1460
+    n = sum(int(np.prod(s)) if len(s) else 1 for s, _, _ in man.values())
+    assert n == 563_541_665
+    assert arch.refiner_manifest(32)["denoiser.idc_conv.weight"][0] == (8192, 2048, 1, 1)
+    assert man["denoiser.middle_blks.3.conv1.weight"][0] == (4096, 2048, 1, 1)
+
+
+def test_synth_is_deterministic_and_scaled():
+    a = synth.make_tensor("denoiser.intro.weight", (128, 4, 3, 3), "conv_w", 36)
+    b = synth.make_tensor("denoiser.intro.weight", (128, 4, 3, 3), "conv_w", 36)
+    assert np.array_equal(a, b) and abs(a).max() <= 1 / 6 + 1e-7
+    g = synth.make_tensor("x.beta", (1, 64, 1, 1), "res_scale", 0)
+    assert g.std() > 0.05                                              # beta/gamma are not zero: blocks are not identities
+    x, crl, crf = synth.sample_inputs(3, 16)
+    x2, _, _ = synth.sample_inputs(2, 16)
+    assert torch.equal(x[:2], x2) and crf.min() >= 0 and crf.max() < 1  # per-face generation: shards see the same faces
+    assert synth.make_state_dict(arch.idc_manifest())["idc.batch_norm1.num_batches_tracked"].shape == ()
+
+
+@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
+def test_scheduler_tables_match_oracle(kind):
+    if kind == "ddim":
+        s, o = schedulers.DDIMScheduler(clip_sample_range=3.0), O.DDIMScheduler(clip_sample=True, clip_sample_range=3.0)
+        s.set_timesteps(50); o.set_timesteps(50)
+    else:
+        s, o = schedulers.DDPMScheduler(clip_sample_range=3.0), O.DDPMScheduler(clip_sample=True, clip_sample_range=3.0)
+    ts, coef = s.coefficient_table()
+    assert [int(t) for t in ts] == o.timesteps
+    assert torch.equal(coef, O.step_coefficients(o, kind))
+    s250 = schedulers.DDIMScheduler(); s250.set_timesteps(250)
+    assert [int(t) for t in s250.timesteps[:2]] == [996, 992]
+    with pytest.raises(NotImplementedError):
+        schedulers.DDIMScheduler(beta_schedule="linear")
+    noisy = s.add_noise(torch.ones(2, 4, 2, 2), torch.zeros(2, 4, 2, 2), torch.tensor([0, 999]))
+    assert torch.allclose(noisy[0], torch.full((4, 2, 2), float(s.alphas_cumprod[0] ** 0.5)))
+
+
+def test_shard_ranges():
+    assert [distributed.shard_range(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]
+    assert [distributed.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert distributed.shard_range(0, 0, 2) == (0, 0)                  # empty batch
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from hifidiff_amd import distributed, synth
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = int(sys.argv[2])
+x, _, _ = synth.sample_inputs(n, 16)
+mine = distributed.shard(x, rank, world) * 2.0 + 1.0          # stand-in for the per-rank sampling result
+full = distributed.gather_faces(mine, n)
+assert full.shape == x.shape and torch.equal(full, x * 2.0 + 1.0), "gather mismatch"
+t = torch.tensor([float(rank)]); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert t.item() == world - 1
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+@pytest.mark.parametrize("n_faces", [4, 5])
+def test_two_rank_shard_and_gather_gloo(tmp_path, n_faces):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + n_faces), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n_faces)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
