@@ -33,6 +33,7 @@ import torch  # noqa: E402
 SURVEY_WEIGHT_BYTES = {16: 722.66e6, 32: 790.28e6}      # effective params x 2 B
 SURVEY_FLOPS_PER_FACE_STEP = {16: 2.0765e9, 32: 8.2917e9}
 HBM_PEAK_GBS = 8000.0                                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")   # rocprofv3 --pmc passes (tools/pmc_traffic.py)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
@@ -159,6 +160,10 @@ def main():
         alg_bytes = SURVEY_WEIGHT_BYTES.get(a.latent, float(wbytes.value))
         step_s = step_ms_avg.value * 1e-3
         achieved = alg_bytes / step_s / 1e9 if step_s > 0 else 0.0
+        traffic, traffic_src = None, None
+        if os.path.exists(TRAFFIC_FILE) and a.latent == 16 and B == 64 and a.kind == "ddpm":
+            tj = json.load(open(TRAFFIC_FILE))
+            traffic, traffic_src = tj["hbm_bytes_per_step"], tj["source"]
         res = {
             "metric": "faces/sec (whole node), 16→128 1000-step reverse diffusion, batch 64",
             "value": round(value, 3), "unit": "faces/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -173,7 +178,7 @@ def main():
                        "launches_per_diffusion_step": Lh.hd_num_ops(model.engine.ctx, 0) * Lh.hd_num_chains(model.engine.ctx) + 1,
                        "output_finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "one captured step graph = one denoiser evaluation of the batch + scheduler update",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "packed_weight_bytes_counted_by_library": int(wbytes.value),

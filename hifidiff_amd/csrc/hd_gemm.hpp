@@ -70,6 +70,7 @@ struct GemmP {
     int ldr;
     int act;                      // 0 none, 1 relu, 2 sigmoid
     int shuffle_r;                // pixel-shuffle factor (1 or 2)
+    int xcd_tile_affine;          // skinny kernel: co-locate the row groups of a weight tile on one XCD
     // fused depthwise 3x3 + SimpleGate + average pool (EpDwGate)
     const float* dw_w;            // [N][9]
     const float* dw_b;            // [N]
@@ -736,13 +737,24 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     constexpr int MT = C::MT, TNT = C::TNT, WK = C::WK, D = C::D, UN = C::UN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WK, wk = wave - wm * WK;
-    const int row0 = blockIdx.x * C::BM;
+    // XCD-aware block -> (row group, weight tile) map: workgroups are dealt round-robin over the 8 XCDs
+    // (private L2s), so all row groups that stream the same weight tile are given ids that are equal mod 8
+    // and adjacent in dispatch order: the tile is fetched from HBM once and re-read from that XCD's L2.
+    // Placement only affects speed, never results.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_tile_affine && (gridDim.y & 7) == 0 && gridDim.x > 1) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int j = lin >> 3;
+        bx = j % (int)gridDim.x;
+        by = (j / (int)gridDim.x) * 8 + (lin & 7);
+    }
+    const int row0 = bx * C::BM;
     const int ksteps_total = p.Kp >> 4;
     const int cpw = (p.Kp >> 6) / WK;                        // host: Kp % (64*WK) == 0
     const int c0 = wk * cpw, c_end = c0 + cpw;
     int tile[TNT];
-    tile[0] = blockIdx.y;
-    if (TNT == 2) tile[1] = blockIdx.y + (p.N >> 6);
+    tile[0] = by;
+    if (TNT == 2) tile[1] = by + (p.N >> 6);
     const uint4* Wl = p.W + lane;
     HD_STAMP(0);
 

@@ -404,6 +404,10 @@ GemmP base_gemm(const PackedW& w, int M) {
 
 void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p, LdKind lk, EpKind ek) {
     int t128 = choose_mode(p, ek == EK_GATE || ek == EK_DWGATE);   // (kernel mode; name kept for the capture list)
+    {   // each XCD re-fetches what its workgroups read: share the bigger operand through the XCD's L2
+        const size_t a_bytes = (size_t)p.M * p.Kp * ((lk == LK_BF16 || lk == LK_BF16S || lk == LK_CONV_BF16) ? 2 : 4);
+        p.xcd_tile_affine = ((size_t)p.N * p.Kp * 2 > a_bytes) ? 1 : 0;
+    }
     if (t128 == 2 && lk == LK_CONV_F32G) t128 = 3;            // the gated gather needs the registers of a 32-row tile
     const bool film = (lk == LK_LN);
     size_t out_rows = (size_t)p.M * (ek == EK_PIXSHUF ? p.shuffle_r * p.shuffle_r : 1);
