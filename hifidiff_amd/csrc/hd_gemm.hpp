@@ -64,6 +64,8 @@ struct GemmP {
     // epilogue
     void* out;
     int ldo;
+    unsigned short* out16;        // optional bf16 copy of `out` (same ld): what the next LayerNorm GEMM reads
+    unsigned short* outg16;       // optional bf16 (out + add_src) * (1 + gate_c[face] + gate_s[row]): the HCA conv input (hca.py:28)
     const float* bias;
     const float* rscale;
     const void* resid;
@@ -184,14 +186,15 @@ struct LdF32Plain {
     }
 };
 
-// fp32 rows -> LayerNorm2d over the row (biased variance, eps inside the sqrt: utils.py:18-22) -> folded
-// LN-affine/FiLM gain and bias (conditional_naf.py:114-115,126-127).  Row statistics come from the
-// producer's partials.
+// bf16 copy of the fp32 residual stream -> LayerNorm2d over the row (biased variance, eps inside the sqrt:
+// utils.py:18-22) -> folded LN-affine/FiLM gain and bias (conditional_naf.py:114-115,126-127).  The row
+// statistics are exact fp32 (producer partials of the unrounded values); only the value being normalised
+// is the bf16 copy, which halves the bytes every workgroup ingests.
 struct LdF32LN {
-    static constexpr int kRawRegs = 8;
-    static constexpr bool kGainBiasLds = true, kSplit = true;
-    struct St { const float* rowp; const float* gain; const float* bias; const float* gbl; float mu, rstd; bool valid; };
-    struct Raw { F8 x; };
+    static constexpr int kRawRegs = 4;
+    static constexpr bool kGainBiasLds = true, kSplit = false;
+    struct St { const unsigned short* rowp; const float* gain; const float* bias; const float* gbl; float mu, rstd; bool valid; };   // mu holds -mean*rstd
+    struct Raw { uint4 x; };
     // (1) merge the producer's per-tile (mean, M2) partials of each row into (mean, rstd) in LDS: 4 threads
     //     per row, Chan's update (Chan, Golub, LeVeque 1979), fixed order -> deterministic;
     // (2) when every row shares one FiLM row (sampling: same t for all faces) copy gain/bias[K] to LDS so
@@ -241,9 +244,9 @@ struct LdF32LN {
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int row_local, const char* stats, const float* gb) {
         st.valid = row < p.M;
         const int r = st.valid ? row : 0;
-        st.rowp = reinterpret_cast<const float*>(p.A) + (size_t)r * p.lda;
+        st.rowp = reinterpret_cast<const unsigned short*>(p.A) + (size_t)r * p.lda;
         const float2 s = reinterpret_cast<const float2*>(stats)[row_local];
-        st.mu = s.x; st.rstd = s.y;
+        st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
         st.gbl = (gb && p.film_face_stride == 0) ? gb : nullptr;      // LDS copy of the shared FiLM row
         const int step = p.step_ptr ? *p.step_ptr : 0;
         const float* f = p.film + (size_t)step * p.film_step_stride + (size_t)(p.face0 + r / p.hw) * p.film_face_stride;
@@ -251,17 +254,21 @@ struct LdF32LN {
         st.bias = f + p.film_bias_off;
     }
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
-        r.x = (st.valid && kc < p.K) ? ldg44(st.rowp + kc + 4 * kq) : zero8();
+        r.x = (st.valid && kc < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
     }
     static __device__ __forceinline__ uint4 finish(const GemmP& p, const St& st, int kc, int kq, const Raw& r) {
         float v[8], g[8], b[8];
         if (!(st.valid && kc < p.K)) return make_uint4(0, 0, 0, 0);
-        f8_to_arr(r.x, v);
-        const int k = kc + 4 * kq;
-        if (st.gbl) { f8_to_arr(ldg44(st.gbl + k), g); f8_to_arr(ldg44(st.gbl + p.Kp + k), b); }
-        else { f8_to_arr(ldg44(st.gain + k), g); f8_to_arr(ldg44(st.bias + k), b); }
+        unpack8(r.x, v);
+        const int k = kc + 8 * kq;
+        const float* gp = st.gbl ? st.gbl + k : st.gain + k;
+        const float* bp = st.gbl ? st.gbl + p.Kp + k : st.bias + k;
+        F8 gg, bb;
+        gg.a = *reinterpret_cast<const float4*>(gp); gg.b = *reinterpret_cast<const float4*>(gp + 4);
+        bb.a = *reinterpret_cast<const float4*>(bp); bb.b = *reinterpret_cast<const float4*>(bp + 4);
+        f8_to_arr(gg, g); f8_to_arr(bb, b);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (v[i] - st.mu) * st.rstd * g[i] + b[i];
+        for (int i = 0; i < 8; ++i) v[i] = fmaf(fmaf(v[i], st.rstd, st.mu), g[i], b[i]);
         return pack8(v);
     }
 };
@@ -400,6 +407,7 @@ struct EpBiasF32 {
     static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float, const ColC& c) {
         v = activate(v + c.bias, p.act);
         reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
+        if (p.out16) p.out16[(size_t)row * p.ldo + col] = f32_to_bf16_bits(v);
         return v;
     }
 };
@@ -413,6 +421,12 @@ struct EpResidF32 {
     static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float r, const ColC& c) {
         v = r + (v + c.bias) * c.rscale;
         reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
+        if (p.out16) p.out16[(size_t)row * p.ldo + col] = f32_to_bf16_bits(v);
+        if (p.outg16) {                                       // f_d * (1 + w_c + w_s) (+ idc term) for the following HCA
+            const float a = p.add_src ? p.add_src[(size_t)row * p.ldo + col] : 0.f;
+            const float g = 1.0f + p.gate_c[(size_t)(row / p.hw) * p.N + col] + p.gate_s[row];
+            p.outg16[(size_t)row * p.ldo + col] = f32_to_bf16_bits((v + a) * g);
+        }
         return v;
     }
 };
@@ -430,12 +444,12 @@ struct EpPixShufF32 {
     static constexpr bool kStats = false, kTile = false;
     static __device__ __forceinline__ ColC col_init(const GemmP&, int) { ColC c; c.bias = 0.f; c.bias2 = 0.f; c.rscale = 1.f; return c; }
     static __device__ __forceinline__ size_t index(const GemmP& p, int row, int col) {
-        if (p.shuffle_r == 2) {
-            const int hw = p.Hin * p.Win;
-            const int b = row / hw, rem = row - b * hw;
-            const int h = rem / p.Win, w = rem - h * p.Win;
+        if (p.shuffle_r == 2) {                                   // Hin == Win == a power of two
+            const int lw = 31 - __builtin_clz(p.Win);
+            const int b = row >> (2 * lw), rem = row & ((1 << (2 * lw)) - 1);
+            const int h = rem >> lw, w = rem & (p.Win - 1);
             const int c = col >> 2, i = (col >> 1) & 1, j = col & 1;
-            return (((size_t)b * (2 * p.Hin) + (2 * h + i)) * (2 * p.Win) + (2 * w + j)) * p.ldo + c;
+            return ((((size_t)b << (lw + 1)) + (2 * h + i)) * (2 * p.Win) + (2 * w + j)) * p.ldo + c;
         }
         return (size_t)row * p.ldo + col;
     }
@@ -680,6 +694,38 @@ struct SkinnyCfg {
     static constexpr int GB_OFF = STATS_OFF + BM * 8;            // + 2*Kp floats of gain/bias for the LN loader
 };
 
+// Depthwise 3x3 + SimpleGate over one image row of S pixels for channel j (both gate halves), window
+// sliding along x.  t1a/t1b point at column j of the two T1 half-tiles ([row][32] floats).  Returns the row
+// sum of the unrounded gate; stores G as bf16.
+template <int S>
+__device__ __forceinline__ float dw_gate_row(const float* t1a, const float* t1b, int p0, bool up, bool dn, const float* wa,
+                                             const float* wb, float ba, float bb, unsigned short* gout, int ldo, bool store_ok,
+                                             int rows_left) {
+    float va[3][S + 2], vb[3][S + 2];                                    // 3 image rows x (S + 2) columns, zero padded
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { va[r][0] = 0.f; va[r][S + 1] = 0.f; vb[r][0] = 0.f; vb[r][S + 1] = 0.f; }
+#pragma unroll
+    for (int x = 0; x < S; ++x) {
+        va[0][x + 1] = up ? t1a[(p0 + x - S) * 32] : 0.f; vb[0][x + 1] = up ? t1b[(p0 + x - S) * 32] : 0.f;
+        va[1][x + 1] = t1a[(p0 + x) * 32];                vb[1][x + 1] = t1b[(p0 + x) * 32];
+        va[2][x + 1] = dn ? t1a[(p0 + x + S) * 32] : 0.f; vb[2][x + 1] = dn ? t1b[(p0 + x + S) * 32] : 0.f;
+    }
+    float rsum = 0.f;
+#pragma unroll
+    for (int x = 0; x < S; ++x) {
+        float u1 = ba, u2 = bb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            u1 += wa[r * 3] * va[r][x] + wa[r * 3 + 1] * va[r][x + 1] + wa[r * 3 + 2] * va[r][x + 2];
+            u2 += wb[r * 3] * vb[r][x] + wb[r * 3 + 1] * vb[r][x + 1] + wb[r * 3 + 2] * vb[r][x + 2];
+        }
+        const float g = u1 * u2;
+        rsum += g;
+        if (store_ok && x < rows_left) gout[(size_t)x * ldo] = f32_to_bf16_bits(g);
+    }
+    return rsum;
+}
+
 template <bool FULL, class C, class EP>
 __device__ __forceinline__ void skinny_rows_epilogue(const GemmP& p, const float* red, int row0, int col, int ncols, int tile_idx, int tid) {
     constexpr int NIT = (C::BM * 32 + C::THREADS - 1) / C::THREADS, TNT = C::TNT, WK = C::WK;
@@ -861,22 +907,23 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         static_assert(TNT == 2, "EpDwGate needs a PAIR tile");
         const int C2 = p.N >> 1;
         // (1) sum the K-split partials in wave order, add conv1's bias, keep T1 in slice 0
-        for (int e = tid; e < C::BM * 32; e += C::THREADS) {
-            const bool rv = (row0 + (e >> 5)) < p.M && col < ncols;
+        //     (rows beyond M hold zeros from the masked A loads; their outputs are never stored)
+        {
+            const float bias_a = col < ncols ? p.bias[col] : 0.f, bias_b = col < ncols ? p.bias[col + C2] : 0.f;
+            for (int e = tid; e < C::BM * 32; e += C::THREADS) {
+                float va = bias_a, vb = bias_b;
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < WK; ++w) v += red[w * TILE_F + tn * C::BM * 32 + e];
-                v += rv ? p.bias[col + tn * C2] : 0.f;
-                red[tn * C::BM * 32 + e] = rv ? v : 0.f;
+                for (int w = 0; w < WK; ++w) { va += red[w * TILE_F + e]; vb += red[w * TILE_F + C::BM * 32 + e]; }
+                red[e] = va; red[C::BM * 32 + e] = vb;
             }
         }
         __syncthreads();
-        // (2) depthwise 3x3 (pad 1) on both halves from LDS, gate, store G (bf16); gate tile to LDS
-        float* gt = reinterpret_cast<float*>(smem + C::GT_OFF);
-        const int j = tid & 31, pg = tid >> 5;
-        const int S = p.side, HW = p.hw;
+        // (2) depthwise 3x3 (pad 1) on both halves from LDS, SimpleGate, store G (bf16).  One work item =
+        //     (channel j, image row): all 3 x (S+2) window values are loaded up front (face side is a
+        //     compile-time power of two), so the LDS latency is paid once per row, not once per pixel.
+        float* rs = reinterpret_cast<float*>(smem + C::GT_OFF);          // [BM / S][32] row sums
+        const int j = tid & 31;
+        const int S = p.side, ls = 31 - __builtin_clz(S), HW = p.hw;     // S in {1,2,4,8,16}
         float wa[9], wb[9], ba = 0.f, bb = 0.f;
         if (col < ncols) {
 #pragma unroll
@@ -886,32 +933,36 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
             for (int t = 0; t < 9; ++t) { wa[t] = 0.f; wb[t] = 0.f; }
         }
-        for (int pr = pg; pr < C::BM; pr += C::THREADS / 32) {
-            const int q = pr % HW, fbase = pr - q;
-            const int y = q / S, x = q - y * S;
-            float u1 = ba, u2 = bb;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if (yy < 0 || yy >= S || xx < 0 || xx >= S) continue;
-                const int pp = fbase + yy * S + xx;
-                u1 += wa[t] * red[pp * 32 + j];
-                u2 += wb[t] * red[(C::BM + pp) * 32 + j];
+        const float* t1a = red + j;
+        const float* t1b = red + C::BM * 32 + j;
+        const int nrows_img = C::BM >> ls;                               // image rows in the tile
+        for (int rr = tid >> 5; rr < nrows_img; rr += C::THREADS / 32) {
+            const int p0 = rr << ls;                                     // first pixel (tile-local row) of this image row
+            const int y = (p0 & (HW - 1)) >> ls;
+            const bool up = y > 0, dn = y < S - 1;
+            const int row = row0 + p0;
+            unsigned short* gout = reinterpret_cast<unsigned short*>(p.out) + (size_t)row * p.ldo + col;
+            const bool ok = col < ncols;
+            const int left = p.M - row;                                  // valid pixels from here on
+            float rsum;
+            switch (S) {
+                case 16: rsum = dw_gate_row<16>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, ok, left); break;
+                case 8: rsum = dw_gate_row<8>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, ok, left); break;
+                case 4: rsum = dw_gate_row<4>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, ok, left); break;
+                case 2: rsum = dw_gate_row<2>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, ok, left); break;
+                default: rsum = dw_gate_row<1>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, ok, left); break;
             }
-            const float g = u1 * u2;
-            gt[pr * 32 + j] = g;
-            const int row = row0 + pr;
-            if (row < p.M && col < ncols) reinterpret_cast<unsigned short*>(p.out)[(size_t)row * p.ldo + col] = f32_to_bf16_bits(g);
+            rs[rr * 32 + j] = rsum;
         }
         __syncthreads();
-        // (3) per-face average pool of the unrounded gate (SCA input)
+        // (3) per-face average pool (SCA input): S row sums per face
         const int faces = C::BM / HW;
         for (int idx = tid; idx < faces * 32; idx += C::THREADS) {
             const int f = idx >> 5;
-            float s = 0.f;
-            for (int q = 0; q < HW; ++q) s += gt[(f * HW + q) * 32 + j];
+            float sacc = 0.f;
+            for (int r = 0; r < S; ++r) sacc += rs[(f * S + r) * 32 + j];
             const int face = row0 / HW + f;
-            if (face * HW < p.M && col < ncols) p.pooled[(size_t)face * C2 + col] = s / (float)HW;
+            if (face * HW < p.M && col < ncols) p.pooled[(size_t)face * C2 + col] = sacc / (float)HW;
         }
     } else {
         // ================= element-wise epilogue, 32 lanes = one row of the tile =================
@@ -976,7 +1027,7 @@ struct ChunkDepth {
     static constexpr int TNT = PAIR ? 2 : 1;
     static constexpr int fixed = MT * TNT * 16 + 48 + MT * 4 * 6;
     static constexpr int per_d = TNT * 16 + MT * 4 * LD::kRawRegs;
-    static constexpr int D = (fixed + 3 * per_d <= 230) ? 3 : ((fixed + 2 * per_d <= 230) ? 2 : 1);
+    static constexpr int D = (fixed + 3 * per_d <= 236) ? 3 : ((fixed + 2 * per_d <= 236) ? 2 : 1);
 };
 
 // Skinny launch, K split over as many waves (<= 8/WM) as keep >= 2 chunks per wave.

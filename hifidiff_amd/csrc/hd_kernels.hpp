@@ -60,7 +60,8 @@ __global__ void pack_weight_kernel(const PackP p) {
 // fp32 FMA (K = 36 is too small for MFMA).  The first thread also advances the loop's step counter.
 __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict__ lat, const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ out,
-                                                          float2* __restrict__ stats, int B, int L, StepState* st, int advance) {
+                                                          unsigned short* __restrict__ out16, float2* __restrict__ stats, int B, int L,
+                                                          StepState* st, int advance) {
     __shared__ float wt[36][128];
     __shared__ float patch[16][36];
     __shared__ float tile[16][128];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 36; ++r) acc += patch[pl][r] * wt[r][co];
         tile[pl][co] = acc;
-        if (pix < M) out[(size_t)pix * 128 + co] = acc;
+        if (pix < M) { out[(size_t)pix * 128 + co] = acc; out16[(size_t)pix * 128 + co] = f32_to_bf16_bits(acc); }
     }
     __syncthreads();
     // LayerNorm statistics of the 128-channel rows for the first block's norm1: (mean, M2), one partial
@@ -106,12 +107,17 @@ __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict
 
 // (mean, M2) over the C channels of every row: LayerNorm statistics for tensors whose producer cannot
 // emit them (pixel-shuffled up-conv outputs).  One wave per row.
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, float2* __restrict__ stats, int M, int C) {
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, unsigned short* __restrict__ X16,
+                                                         float2* __restrict__ stats, int M, int C) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* rp = X + (size_t)row * C;
     float s = 0.f;
-    for (int k = lane * 4; k < C; k += 256) { const float4 v = *reinterpret_cast<const float4*>(rp + k); s += (v.x + v.y) + (v.z + v.w); }
+    for (int k = lane * 4; k < C; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(rp + k);
+        s += (v.x + v.y) + (v.z + v.w);
+        *reinterpret_cast<uint2*>(X16 + (size_t)row * C + k) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));   // bf16 copy for the LN GEMM
+    }
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
     for (int k = lane * 4; k < C; k += 256) {

@@ -66,7 +66,7 @@ struct Op {
     int out_bf16 = 0;
 };
 
-struct Level { int C, H, M; float *X, *Y, *T1, *pooled, *S; unsigned short* G; float2 *sx, *sy; };
+struct Level { int C, H, M; float *X, *Y, *T1, *pooled, *S; unsigned short *G, *Xb, *Yb, *Xg; float2 *sx, *sy; };
 
 }  // namespace
 
@@ -333,7 +333,8 @@ int pack_weight(hd_ctx* c, const std::string& name, PackedW* out, const PackOpts
 }
 
 // ------------------------------------------------------------------------------------ GEMM dispatch
-// mode: 0 = tall T128, 1 = tall T64, 2 = skinny 64 rows, 3 = skinny 32 rows, 4 = tall T32W (32 rows x 256 cols)
+// mode: 0 = tall T128, 1 = tall T64, 2 = skinny 64 rows, 3 = skinny 32 rows, 4 = tall T32W (32 rows x 256 cols),
+//       5 / 6 = skinny with 4 / 8 M-split waves (128 / 256 rows per workgroup; long-K gathers at large M)
 template <class LD, class EP, bool PAIR>
 hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
     if constexpr (PAIR) {
@@ -342,6 +343,8 @@ hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
             case 1: return launch_gemm<T64P, LD, EP>(p, s);
             case 2: return launch_skinny_auto<1, 2, true, LD, EP>(p, s);
             case 4: return launch_gemm<T32WP, LD, EP>(p, s);
+            case 5: return launch_skinny_auto<4, 1, true, LD, EP>(p, s);
+            case 6: return launch_skinny_auto<8, 1, true, LD, EP>(p, s);
             default: return launch_skinny_auto<1, 1, true, LD, EP>(p, s);
         }
     } else {
@@ -350,6 +353,8 @@ hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
             case 1: return launch_gemm<T64, LD, EP>(p, s);
             case 2: return launch_skinny_auto<1, 2, false, LD, EP>(p, s);
             case 4: return launch_gemm<T32W, LD, EP>(p, s);
+            case 5: return launch_skinny_auto<4, 1, false, LD, EP>(p, s);
+            case 6: return launch_skinny_auto<8, 1, false, LD, EP>(p, s);
             default: return launch_skinny_auto<1, 1, false, LD, EP>(p, s);
         }
     }
@@ -373,8 +378,8 @@ hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStre
     if (lk == LK_BF16S && ek == EK_RESID) return launch_tile<LdBF16Scale, EpResidF32, false>(p, mode, s);
     if (lk == LK_BF16 && ek == EK_RESID) return launch_tile<LdBF16Plain, EpResidF32, false>(p, mode, s);
     if (lk == LK_BF16 && ek == EK_BIASBF16) return launch_tile<LdBF16Plain, EpBiasBF16, false>(p, mode, s);
-    if (lk == LK_CONV_F32 && ek == EK_BIASF32) return launch_tile<LdConv<false, false>, EpBiasF32, false>(p, mode, s);
-    if (lk == LK_CONV_F32G && ek == EK_BIASF32) return launch_tile<LdConv<false, true>, EpBiasF32, false>(p, mode, s);
+    if (lk == LK_CONV_BF16 && ek == EK_BIASF32) return launch_tile<LdConv<true, false>, EpBiasF32, false>(p, mode, s);
+    if (lk == LK_BF16 && ek == EK_PIXSHUF) return launch_tile<LdBF16Plain, EpPixShufF32, false>(p, mode, s);
     if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, mode, s);
     return hipErrorInvalidValue;
 }
@@ -389,6 +394,10 @@ int choose_mode(const GemmP& p, bool pair) {
     if (force >= 0) return force;
     const int nb256 = (ncols + (pair ? 127 : 255)) / (pair ? 128 : 256);
     if (p.Kp <= 256 && nb256 <= 2 && ((p.M + 31) / 32) * nb256 >= 512) return 4;   // levels 0/1 at full batch
+    if (p.Kp >= 1024 && p.M >= 2048) {                      // long-K gathers (HCA 3x3 at levels 0/1): chunks stay in flight per wave
+        if (((p.M + 255) / 256) * nb32 >= 256) return 6;
+        if (((p.M + 127) / 128) * nb32 >= 192) return 5;
+    }
     if (((p.M + 127) / 128) * nb64 >= 256) return 0;
     if (((p.M + 63) / 64) * nb64 >= 256) return 1;
     if (((p.M + 63) / 64) * nb32 >= 192) return 2;
@@ -405,10 +414,9 @@ GemmP base_gemm(const PackedW& w, int M) {
 void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p, LdKind lk, EpKind ek) {
     int t128 = choose_mode(p, ek == EK_GATE || ek == EK_DWGATE);   // (kernel mode; name kept for the capture list)
     {   // each XCD re-fetches what its workgroups read: share the bigger operand through the XCD's L2
-        const size_t a_bytes = (size_t)p.M * p.Kp * ((lk == LK_BF16 || lk == LK_BF16S || lk == LK_CONV_BF16) ? 2 : 4);
+        const size_t a_bytes = (size_t)p.M * p.Kp * ((lk == LK_BF16 || lk == LK_BF16S || lk == LK_CONV_BF16 || lk == LK_LN) ? 2 : 4);
         p.xcd_tile_affine = ((size_t)p.N * p.Kp * 2 > a_bytes) ? 1 : 0;
     }
-    if (t128 == 2 && lk == LK_CONV_F32G) t128 = 3;            // the gated gather needs the registers of a 32-row tile
     const bool film = (lk == LK_LN);
     size_t out_rows = (size_t)p.M * (ek == EK_PIXSHUF ? p.shuffle_r * p.shuffle_r : 1);
     Op op;
@@ -432,8 +440,9 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
 // static_film: FPG blocks use the LayerNorm affine itself as the "FiLM" row (scale = shift = 0).
 // x_np/x_cnt: how the LayerNorm partials of the block input X were produced (C/32 x 32 by a GEMM
 // epilogue, 1 x C by intro / row_stats); on return they describe conv5's output.
+struct GateOut { const float* gate_c = nullptr; const float* gate_s = nullptr; const float* add = nullptr; };
 void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Level& lv, const float* static_film, int* x_np,
-                   int* x_cnt) {
+                   int* x_cnt, const GateOut* gate = nullptr) {
     const int C = bw.C, M = lv.M, HW = lv.H * lv.H;
     auto film_fields = [&](GemmP& p, int half) {
         p.hw = HW; p.face0 = c->ch->face0;
@@ -446,14 +455,14 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
     if (dwgate_ok(HW) && !no_fuse) {
         // LN1 + FiLM -> conv1 (+bias) -> depthwise 3x3 -> SimpleGate -> G, pooled mean: one launch
         GemmP p = base_gemm(bw.conv1, M);
-        p.A = lv.X; p.lda = C; film_fields(p, 0);
+        p.A = lv.Xb; p.lda = C; film_fields(p, 0);
         p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
         p.out = lv.G; p.ldo = C; p.dw_w = bw.dw_w; p.dw_b = bw.dw_b; p.pooled = lv.pooled; p.side = lv.H;
         add_gemm(c, prog, bw.name + ".conv2_gate_pool", p, LK_LN, EK_DWGATE);
     } else {
         {   // LN1 + FiLM -> conv1 (+bias) -> T1
             GemmP p = base_gemm(bw.conv1, M);
-            p.A = lv.X; p.lda = C; film_fields(p, 0);
+            p.A = lv.Xb; p.lda = C; film_fields(p, 0);
             p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
             p.out = lv.T1; p.ldo = 2 * C;
             add_gemm(c, prog, bw.name + ".conv1", p, LK_LN, EK_BIASF32);
@@ -478,12 +487,12 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         GemmP p = base_gemm(bw.conv3, M);
         p.A = lv.G; p.lda = C; p.hw = HW; p.rowscale = lv.S;
         p.out = lv.Y; p.ldo = C; p.resid = lv.X; p.ldr = C; p.rscale = bw.beta;
-        p.stats_out = lv.sy;
+        p.stats_out = lv.sy; p.out16 = lv.Yb;
         add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16S, EK_RESID);
     }
     {   // LN2 + FiLM -> conv4 -> SimpleGate -> G2 (bf16, reuses G)
         GemmP p = base_gemm(bw.conv4, M);
-        p.A = lv.Y; p.lda = C; film_fields(p, 1);
+        p.A = lv.Yb; p.lda = C; film_fields(p, 1);
         p.stats_in = lv.sy; p.stats_np = C / 32; p.stats_cnt = 32;
         p.out = lv.G; p.ldo = C;
         add_gemm(c, prog, bw.name + ".conv4", p, LK_LN, EK_GATE);
@@ -492,17 +501,21 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         GemmP p = base_gemm(bw.conv5, M);
         p.A = lv.G; p.lda = C;
         p.out = lv.X; p.ldo = C; p.resid = lv.Y; p.ldr = C; p.rscale = bw.gamma;
-        p.stats_out = lv.sx;
+        p.stats_out = lv.sx; p.out16 = lv.Xb;
+        if (gate) {                                         // last block before an HCA: also emit the gated conv input
+            p.outg16 = lv.Xg; p.gate_c = gate->gate_c; p.gate_s = gate->gate_s; p.add_src = gate->add; p.hw = HW;
+            p.stats_out = nullptr; p.out16 = nullptr;       // nothing normalises this tensor next
+        }
         add_gemm(c, prog, bw.name + ".conv5", p, LK_BF16, EK_RESID);
     }
     *x_np = C / 32; *x_cnt = 32;
 }
 
-void add_row_stats(std::vector<Op>& prog, const std::string& name, const float* X, float2* stats, int M, int C) {
+void add_row_stats(std::vector<Op>& prog, const std::string& name, const float* X, unsigned short* X16, float2* stats, int M, int C) {
     Op op;
     op.name = name;
     op.run = [=](hipStream_t s) -> hipError_t {
-        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, stats, M, C);
+        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, X16, stats, M, C);
         return hipGetLastError();
     };
     prog.push_back(op);
@@ -510,30 +523,31 @@ void add_row_stats(std::vector<Op>& prog, const std::string& name, const float* 
 
 void add_down(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const Level& src, const Level& dst) {
     GemmP p = base_gemm(w, dst.M);                      // Conv2d(C, 2C, 2, 2) as a patch-gather GEMM
-    p.A = src.X; p.lda = src.C; p.Hin = src.H; p.Win = src.H; p.Cin = src.C; p.KH = 2; p.KW = 2; p.stride = 2; p.pad = 0;
-    p.Hout = dst.H; p.Wout = dst.H; p.ntaps = 4;
-    p.out = dst.X; p.ldo = dst.C; p.stats_out = dst.sx;
-    add_gemm(c, prog, name, p, LK_CONV_F32, EK_BIASF32);
+    p.A = src.Xb; p.lda = src.C; p.Hin = src.H; p.Win = src.H; p.Cin = src.C; p.KH = 2; p.KW = 2; p.stride = 2; p.pad = 0;
+    p.Hout = dst.H; p.Wout = dst.H; p.ntaps = 4;          // gathers the bf16 copy conv5 wrote (same rounding point as before)
+    p.out = dst.X; p.ldo = dst.C; p.stats_out = dst.sx; p.out16 = dst.Xb;
+    add_gemm(c, prog, name, p, LK_CONV_BF16, EK_BIASF32);
 }
 
 // 1x1 conv (no bias) + PixelShuffle(r) + skip add, written in place over the skip buffer
-void add_up(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const float* in, int M_in, int H_in,
-            int C_in, float* out, const float* skip, int r) {
+void add_up(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const void* in, bool in_bf16, int M_in,
+            int H_in, int C_in, float* out, const float* skip, int r) {
     GemmP p = base_gemm(w, M_in);
     p.A = in; p.lda = C_in; p.Hin = H_in; p.Win = H_in; p.shuffle_r = r;
     p.out = out; p.ldo = w.N / (r * r); p.resid = skip; p.bias = nullptr;
-    add_gemm(c, prog, name, p, LK_F32, EK_PIXSHUF);
+    add_gemm(c, prog, name, p, in_bf16 ? LK_BF16 : LK_F32, EK_PIXSHUF);
 }
 
-void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const HcaW& hw, int idx, const float* in, const float* add,
-             float* out, int M, int H) {
+// HCA conv on the pre-gated bf16 tensor Xg that the preceding conv5 epilogue wrote (hca.py:28-29,21-23): a
+// plain bf16 implicit GEMM; BN folded, ReLU; fp32 output (+ bf16 copy for the up-conv that follows).
+void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const HcaW& hw, const unsigned short* in, float* out,
+             unsigned short* out16, int M, int H) {
     GemmP p = base_gemm(hw.fused, M);
     p.A = in; p.lda = hw.C; p.Hin = H; p.Win = H; p.Cin = hw.C; p.Hout = H; p.Wout = H; p.stride = 1;
     if (hw.centre_only) { p.KH = 1; p.KW = 1; p.pad = 0; p.ntaps = 1; }
     else { p.KH = 3; p.KW = 3; p.pad = 1; p.ntaps = 9; }
-    p.gate_c = c->ch->gate_c[idx]; p.gate_s = c->ch->gate_s[idx]; p.add_src = add;
-    p.out = out; p.ldo = hw.C; p.act = 1;
-    add_gemm(c, prog, name, p, LK_CONV_F32G, EK_BIASF32);
+    p.out = out; p.ldo = hw.C; p.act = 1; p.out16 = out16;
+    add_gemm(c, prog, name, p, LK_CONV_BF16, EK_BIASF32);
 }
 
 int run_ops(hd_ctx* c, std::vector<Op>& prog, hipStream_t s, int limit = -1) {
@@ -559,6 +573,7 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
         rc |= dev_alloc(c, &v.X, mc); rc |= dev_alloc(c, &v.Y, mc); rc |= dev_alloc(c, &v.T1, 2 * mc);
         rc |= dev_alloc(c, &v.G, mc); rc |= dev_alloc(c, &v.pooled, (size_t)B * v.C); rc |= dev_alloc(c, &v.S, (size_t)B * v.C);
         rc |= dev_alloc(c, &v.sx, (size_t)v.M * (v.C / 32)); rc |= dev_alloc(c, &v.sy, (size_t)v.M * (v.C / 32));
+        rc |= dev_alloc(c, &v.Xb, mc); rc |= dev_alloc(c, &v.Yb, mc); rc |= dev_alloc(c, &v.Xg, mc);
         const int pi = 4 - l;                            // prior index: coarsest first
         rc |= dev_alloc(c, &ch.prior[pi], mc); rc |= dev_alloc(c, &ch.gate_c[pi], (size_t)B * v.C);
         rc |= dev_alloc(c, &ch.gate_s[pi], (size_t)v.M);
@@ -634,9 +649,10 @@ int build_denoiser_program(hd_ctx* c) {
     const RawTensor *ew = find_raw(c, "denoiser.ending.weight"), *eb = find_raw(c, "denoiser.ending.bias");
     {
         const float *lat = c->ch->lat, *w = iw->dev, *b = ib->dev; float* out = c->ch->lv[0].X; float2* sx = c->ch->lv[0].sx;
+        unsigned short* xb = c->ch->lv[0].Xb;
         const int M = c->ch->lv[0].M;
         prog.push_back({"intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, lat, w, b, out, sx, B, L, chp->step_state, c->advance);
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
@@ -649,17 +665,23 @@ int build_denoiser_program(hd_ctx* c) {
         add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
         np = c->ch->lv[l + 1].C / 32; cnt = 32;
     }
-    for (int j = 0; j < 8; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[4], nullptr, &np, &cnt);
-    // x + idc_conv(id) -> HCA0 (model.py:245-247); the add is folded into the HCA loader
-    add_hca(c, prog, "hcas.0", c->hca[0], 0, c->ch->lv[4].X, c->ch->idc_term, c->ch->lv[4].Y, c->ch->lv[4].M, c->ch->lv[4].H);
+    // x + idc_conv(id) -> HCA0 (model.py:245-247): the add and the gate are applied by the last mid block's conv5 epilogue
+    for (int j = 0; j < 8; ++j) {
+        GateOut g0; g0.gate_c = c->ch->gate_c[0]; g0.gate_s = c->ch->gate_s[0]; g0.add = c->ch->idc_term;
+        add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[4], nullptr, &np, &cnt, j == 7 ? &g0 : nullptr);
+    }
+    add_hca(c, prog, "hcas.0", c->hca[0], c->ch->lv[4].Xg, c->ch->lv[4].Y, c->ch->lv[4].Yb, c->ch->lv[4].M, c->ch->lv[4].H);
     for (int i = 0; i < 4; ++i) {
         const int l = 3 - i;
         const Level &hi = c->ch->lv[l + 1], &lo = c->ch->lv[l];
-        add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], hi.Y, hi.M, hi.H, hi.C, lo.X, lo.X, 2);
-        add_row_stats(prog, "ups." + std::to_string(i) + ".row_stats", lo.X, lo.sx, lo.M, lo.C);
+        add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], hi.Yb, true, hi.M, hi.H, hi.C, lo.X, lo.X, 2);
+        add_row_stats(prog, "ups." + std::to_string(i) + ".row_stats", lo.X, lo.Xb, lo.sx, lo.M, lo.C);
         np = 1; cnt = lo.C;
-        for (int j = 0; j < 2; ++j) add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt);
-        add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], i + 1, lo.X, nullptr, lo.Y, lo.M, lo.H);
+        for (int j = 0; j < 2; ++j) {
+            GateOut g; g.gate_c = c->ch->gate_c[i + 1]; g.gate_s = c->ch->gate_s[i + 1];
+            add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt, j == 1 ? &g : nullptr);
+        }
+        add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
     }
     {
         const float *X = c->ch->lv[0].Y, *w = ew->dev, *b = eb->dev; float* eps = c->ch->eps;
@@ -710,9 +732,10 @@ void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
     const RawTensor *iw = find_raw(c, "fpg.intro.weight"), *ib = find_raw(c, "fpg.intro.bias");
     {
         const float *w = iw->dev, *b = ib->dev; float* out = c->ch->lv[0].X; const int M = c->ch->lv[0].M; float2* sx = c->ch->lv[0].sx;
+        unsigned short* xb = c->ch->lv[0].Xb;
         Chain* chp = c->ch;
         prog.push_back({"fpg.intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, cr_latent_dev, w, b, out, sx, B, L, chp->step_state, 0);
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, cr_latent_dev, w, b, out, xb, sx, B, L, chp->step_state, 0);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
@@ -726,7 +749,7 @@ void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
         np = c->ch->lv[l + 1].C / 32; cnt = 32;
     }
     // convs[0]: 1x1, PixelShuffle(1) == identity -> prior0; then 4x (1x1, PixelShuffle(2), + enc skip)
-    add_up(c, prog, "fpg.convs.0", c->fpg_convs[0], c->ch->lv[4].X, c->ch->lv[4].M, c->ch->lv[4].H, c->ch->lv[4].C, c->ch->prior[0], nullptr, 1);
+    add_up(c, prog, "fpg.convs.0", c->fpg_convs[0], c->ch->lv[4].X, false, c->ch->lv[4].M, c->ch->lv[4].H, c->ch->lv[4].C, c->ch->prior[0], nullptr, 1);
     for (int i = 1; i < 5; ++i) {
         const Level &hi = c->ch->lv[5 - i], &lo = c->ch->lv[4 - i];
         // out = shuffled + skip: write into prior[i] with the encoder output as the additive source

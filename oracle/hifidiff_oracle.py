@@ -77,11 +77,14 @@ def _conv_bn(x, P, conv, bn, prec, stride=1, padding=0, gemm=True):
 
 
 # --------------------------------------------------------------------------------------- primitives
-def layernorm2d(x, w, b, eps=1e-6):
-    """Per-pixel LayerNorm over channels, biased variance (reference utils.py:16-24, eps utils.py:47)."""
+def layernorm2d(x, w, b, eps=1e-6, prec=None):
+    """Per-pixel LayerNorm over channels, biased variance (reference utils.py:16-24, eps utils.py:47).
+    bf16 emulation: the statistics come from the fp32 values, the value being normalised is the bf16 copy
+    of the residual stream that the HIP loader reads."""
     mu = x.mean(1, keepdim=True)
     var = (x - mu).pow(2).mean(1, keepdim=True)
-    y = (x - mu) / (var + eps).sqrt()
+    xv = prec.q(x) if prec is not None else x
+    y = (xv - mu) / (var + eps).sqrt()
     return w.view(1, -1, 1, 1) * y + b.view(1, -1, 1, 1)
 
 
@@ -124,7 +127,7 @@ def _tap(taps, name, x):
 def _naf_body(P, p, inp, film, prec, taps=None):
     """Shared body of ConditionalNAFBlock.forward (conditional_naf.py:108-136) and NAFBlock.forward
     (models/fpg/naf.py:105-126); `film` is None for the plain block."""
-    x = layernorm2d(inp, P[p + ".norm1.weight"], P[p + ".norm1.bias"])
+    x = layernorm2d(inp, P[p + ".norm1.weight"], P[p + ".norm1.bias"], prec=prec)
     if film is not None:
         x = x * (film[1] + 1) + film[0]
     x = _gemm_conv(x, P[p + ".conv1.weight"], P[p + ".conv1.bias"], prec)
@@ -140,7 +143,7 @@ def _naf_body(P, p, inp, film, prec, taps=None):
     x = _gemm_conv(x, P[p + ".conv3.weight"], P[p + ".conv3.bias"], prec)
     y = inp + x * P[p + ".beta"]
     _tap(taps, p + ".conv3", y)
-    x = layernorm2d(y, P[p + ".norm2.weight"], P[p + ".norm2.bias"])
+    x = layernorm2d(y, P[p + ".norm2.weight"], P[p + ".norm2.bias"], prec=prec)
     if film is not None:
         x = x * (film[3] + 1) + film[2]
     x = _gemm_conv(x, P[p + ".conv4.weight"], P[p + ".conv4.bias"], prec)

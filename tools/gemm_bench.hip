@@ -25,7 +25,7 @@ __global__ void fillf_kernel(float* p, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v * (float)((i * 7919) % 1000) / 1000.f;
 }
 // floor: stream the weight bytes only (16 B per lane, everything in flight)
-__global__ __launch_bounds__(256) void stream_kernel(const uint4* w, size_t n16, unsigned* sink) {
+__global__ __launch_bounds__(512) void stream_kernel(const uint4* w, size_t n16, unsigned* sink) {
     unsigned acc = 0;
     const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
     const size_t b = (size_t)blockIdx.x * per, e = b + per < n16 ? b + per : n16;
@@ -122,6 +122,41 @@ int main(int argc, char** argv) {
           report_stamps(stamps, nwg); }                                                                  \
     }
     if (K % 512 == 0 && M <= 1024) {
+        // ---- do two streams of graph-replayed launches overlap? (N = 2048 uses 128 workgroups per launch)
+        hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        hipStream_t s1; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+        auto capture = [&](hipStream_t st, int rot0) {
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < 50; ++i) { GemmP p = base(rot0 + i); p.A = Ab; p.lda = K; (void)launch_skinny<SkinnyCfg<1, 8, 1, false, 2>, LdBF16Plain, EpResidF32>(p, st); }
+            CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0)); CK(hipGraphDestroy(g));
+            return ge;
+        };
+        hipGraphExec_t ga = capture(s1, 0), gb = capture(s2, 40);
+        hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+        CK(hipGraphLaunch(ga, s1)); CK(hipGraphLaunch(gb, s2)); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, s1)); for (int r = 0; r < 4; ++r) CK(hipGraphLaunch(ga, s1)); CK(hipEventRecord(e1, s1)); CK(hipDeviceSynchronize());
+        float one; CK(hipEventElapsedTime(&one, e0, e1));
+        CK(hipEventRecord(e0, s1)); CK(hipStreamWaitEvent(s2, e0, 0));
+        for (int r = 0; r < 4; ++r) { CK(hipGraphLaunch(ga, s1)); CK(hipGraphLaunch(gb, s2)); }
+        CK(hipEventRecord(e2, s2)); CK(hipStreamWaitEvent(s1, e2, 0)); CK(hipEventRecord(e1, s1)); CK(hipDeviceSynchronize());
+        float two; CK(hipEventElapsedTime(&two, e0, e1));
+        {   // pure kernel-boundary cost: chains of trivial kernels of different shapes in a graph
+            auto chain = [&](int wgs, int thr, int lds) {
+                hipGraph_t g; hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(s1, hipStreamCaptureModeThreadLocal));
+                for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(stream_kernel, dim3(wgs), dim3(thr), lds, s1, b.W[0], (size_t)64, sink);
+                CK(hipStreamEndCapture(s1, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0)); CK(hipGraphDestroy(g));
+                CK(hipGraphLaunch(ge, s1)); CK(hipStreamSynchronize(s1));
+                CK(hipEventRecord(e0, s1)); for (int r = 0; r < 4; ++r) CK(hipGraphLaunch(ge, s1)); CK(hipEventRecord(e1, s1)); CK(hipStreamSynchronize(s1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("trivial-kernel chain in a graph: %4d WG x %4d thr, %6d B LDS: %.2f us per launch\n", wgs, thr, lds, ms * 1000 / 400);
+            };
+            chain(1, 64, 0); chain(256, 256, 0); chain(128, 512, 0); chain(128, 512, 60000); chain(1024, 256, 0);
+        }
+        printf("graph replay, 200 launches on one stream: %.2f us/launch; 2 x 200 on two streams: %.2f us per pair (%.2fx throughput)\n",
+               one * 1000 / 200, two * 1000 / 200, 2 * one / two);
+
         RUN_SK("skinny bf16plain resid MT1 W8 D4", 1, 8, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
         RUN_SK("skinny bf16plain resid MT1 W8 D2", 1, 8, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
         RUN_SK("skinny bf16plain resid MT1 W4 D4", 1, 4, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
@@ -130,10 +165,10 @@ int main(int argc, char** argv) {
         RUN_SK("skinny f32plain bias  MT1 W8 D2", 1, 8, false, 2, LdF32Plain, EpBiasF32, (p.A = b.A, p.lda = K))
         RUN_SK("skinny f32plain bias  MT1 W8 D4", 1, 8, false, 4, LdF32Plain, EpBiasF32, (p.A = b.A, p.lda = K))
         RUN_SK("skinny bf16scale resid MT1 W8 D2", 1, 8, false, 2, LdBF16Scale, EpResidF32, (p.A = Ab, p.lda = K, p.rowscale = b.rowscale))
-        RUN_SK("skinny LN bias MT1 W8 D2", 1, 8, false, 2, LdF32LN, EpBiasF32, (p.A = b.A, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
-        RUN_SK("skinny LN bias MT1 W8 D4", 1, 8, false, 4, LdF32LN, EpBiasF32, (p.A = b.A, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
-        RUN_SK("skinny LN gate(pair) MT1 W8 D2", 1, 8, true, 2, LdF32LN, EpGateBF16, (p.A = b.A, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
-        RUN_SK("skinny LN gate(pair) MT2 W8 D1", 2, 8, true, 1, LdF32LN, EpGateBF16, (p.A = b.A, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny LN bias MT1 W8 D2", 1, 8, false, 2, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
+        RUN_SK("skinny LN bias MT1 W8 D4", 1, 8, false, 4, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
+        RUN_SK("skinny LN gate(pair) MT1 W8 D2", 1, 8, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny LN gate(pair) MT2 W8 D1", 2, 8, true, 1, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
     }
 #define RUN_TALL(name, CFG, LD, EP, setup)                                                               \
     {                                                                                                    \
@@ -145,14 +180,37 @@ int main(int argc, char** argv) {
           const int nwg = ((M + CFG::BM - 1) / CFG::BM) * ((nc + CFG::NCOLS - 1) / CFG::NCOLS);          \
           report_stamps(stamps, nwg < 8192 ? nwg : 8192); }                                              \
     }
+#define RUN_SKW(name, WM, WK, MT, PAIR, D, LD, EP, setup)                                                 \
+    {                                                                                                    \
+        float us = time_it([&](int i) { GemmP p = base(i); setup; hipError_t e = launch_skinny<SkinnyCfg<WM, WK, MT, PAIR, D>, LD, EP>(p, s); if (e != hipSuccess) { printf("launch failed %s\n", hipGetErrorString(e)); exit(1);} }, iters, s); \
+        printf("%-44s %8.2f us", name, us);                                                             \
+        { GemmP p = base(7); setup; p.stamps = stamps; CK(hipMemsetAsync(stamps, 0, 8192 * 64, s));     \
+          (void)launch_skinny<SkinnyCfg<WM, WK, MT, PAIR, D>, LD, EP>(p, s); CK(hipStreamSynchronize(s)); \
+          const int nwg = ((M + 32 * MT * WM - 1) / (32 * MT * WM)) * (((PAIR) ? N / 2 : N) / 32);       \
+          report_stamps(stamps, nwg < 8192 ? nwg : 8192); }                                              \
+    }
+    if (M >= 2048 && N >= 256) {
+        float* pooled; CK(hipMalloc(&pooled, (size_t)(M / 16) * N * 4));
+        float* dww; CK(hipMalloc(&dww, (size_t)N * 9 * 4)); hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, dww, (size_t)N * 9, 0.3f);
+        const int hw = (M == 16384) ? 256 : 64, side = (M == 16384) ? 16 : 8;
+        if (hw == 256) {
+            RUN_SKW("skinny WM8 LN dwgate (L0 conv1 fused)", 8, 1, 1, true, 1, LdF32LN, EpDwGate, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = hw, p.side = side))
+            RUN_SKW("skinny WM8 LN gate (no dw)", 8, 1, 1, true, 1, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.hw = hw))
+            RUN_SKW("skinny WM8 D2 LN gate (no dw)", 8, 1, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.hw = hw))
+        } else {
+            RUN_SKW("skinny WM2 WK2 LN dwgate (L1 conv1 fused)", 2, 2, 1, true, 1, LdF32LN, EpDwGate, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = hw, p.side = side))
+        }
+        RUN_SKW("skinny WM4 bf16plain resid +stats", 4, 1, 1, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
+        RUN_SKW("skinny WM8 bf16plain resid +stats", 8, 1, 1, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
+    }
     if (M >= 2048) {
         RUN_TALL("tall T32W bf16plain resid", T32W, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
         RUN_TALL("tall T32W bf16plain resid (no stats)", T32W, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
         RUN_TALL("tall T64  bf16plain resid", T64, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
         RUN_TALL("tall T128 bf16plain resid", T128, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
         RUN_TALL("tall T128 bf16scale resid", T128, LdBF16Scale, EpResidF32, (p.A = Ab, p.lda = K, p.rowscale = b.rowscale, p.hw = 256, p.stats_out = b.stats_out))
-        RUN_TALL("tall T128 LN bias", T128, LdF32LN, EpBiasF32, (p.A = b.A, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
-        RUN_TALL("tall T128P LN gate", T128P, LdF32LN, EpGateBF16, (p.A = b.A, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_TALL("tall T128 LN bias", T128, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
+        RUN_TALL("tall T128P LN gate", T128P, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
     }
     return 0;
 }
