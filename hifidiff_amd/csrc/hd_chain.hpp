@@ -1,0 +1,262 @@
+// hd_chain.hpp — the row-local tail of a (Conditional)NAFBlock as ONE kernel, for the levels whose channel
+// count fits a workgroup (C = 128 or 256: levels 0/1):
+//
+//   s = sca(pooled)                               per-face GEMV on the MFMA (conditional_naf.py:54-65,119)
+//   y = x + beta * conv3(g * s)                   (conditional_naf.py:119-123)
+//   a = LN(y) * (1 + scale_ffn) + shift_ffn       (utils.py:16-24, conditional_naf.py:126-127)
+//   x' = y + gamma * conv5(gate(conv4(a)))        (conditional_naf.py:128-134)
+//
+// A workgroup owns 32 pixel rows (inside one face) and ALL channels, so nothing here needs another
+// workgroup: y, the LayerNorm statistics, the normalised tile and the gated tile live in LDS; only x' (fp32),
+// its bf16 copy, the per-tile LayerNorm partials for the next block and (optionally) the HCA-gated copy go to
+// memory.  Replaces four launches (sca, conv3, conv4, conv5).  Rounding points are those of the unfused path.
+#pragma once
+#include "hd_gemm.hpp"
+
+namespace hd {
+
+struct ChainP {
+    int M, hw, face0;                 // rows, rows per face, first face of this launch in the batch
+    const unsigned short* G;          // [M][C] bf16 gate output of the fused conv1 kernel
+    const float* pooled;              // [faces][C]
+    const float* X;                   // [M][C] block input (residual)
+    const uint4 *Wsca, *W3, *W4, *W5; // packed bf16 weights (K = C)
+    const float *bsca, *b3, *b4, *b5, *beta, *gamma;
+    const float* film;                // FiLM table; this block's [bias_ffn | gain_ffn] at film_bias_off / film_gain_off
+    int film_face_stride, film_step_stride, film_gain_off, film_bias_off;
+    const int* step_ptr;
+    float ln_eps;
+    float* Xout;                      // [M][C] fp32
+    unsigned short* Xout16;           // bf16 copy (next LayerNorm GEMM / down conv), or NULL
+    float2* stats_out;                // [M][C/32] (mean, M2) partials of x', or NULL
+    unsigned short* outg16;           // HCA-gated copy (x' + add) * (1 + w_c + w_s), or NULL
+    const float *gate_c, *gate_s, *add_src;
+};
+
+template <int C>
+struct ChainCfg {
+    static constexpr int NT = C / 32;                    // 32-column tiles of a C-wide output
+    static constexpr int WAVES = NT, THREADS = 64 * WAVES, BM = 32;   // one column tile per wave (4 waves at C=128, 8 at C=256)
+    static constexpr int TPW = 1;
+    static constexpr int KS = C / 16;                    // k-steps of a K = C GEMM
+    static constexpr int AROW = C * 2 + 16;              // bytes per bf16 A-tile row (padded)
+    static constexpr int YROW = C + 4;                   // floats per y row (padded)
+    static constexpr int A1_OFF = 0;                     // A tile of conv3 / later of conv5 (gated conv4 output)
+    static constexpr int A2_OFF = A1_OFF + BM * AROW;    // A tile of conv4 (normalised y)
+    static constexpr int Y_OFF = A2_OFF + BM * AROW;     // y tile fp32
+    static constexpr int S_OFF = Y_OFF + BM * YROW * 4;  // sca vector [C]
+    static constexpr int GB_OFF = S_OFF + C * 4;         // FiLM gain | bias [2][C]
+    static constexpr int SMEM = GB_OFF + 2 * C * 4;
+    static_assert(TPW >= 1, "C must be a multiple of 128");
+};
+
+// All B fragments of one column tile (K = C) are requested at once: a GEMM of the chain costs one memory
+// round trip, and the next GEMM's weights are requested before the current epilogue / barrier.
+template <int C>
+__device__ __forceinline__ void chain_load_b(const uint4* W, int tile, int lane, uint4* b) {
+    const uint4* Wl = W + (size_t)tile * ChainCfg<C>::KS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < ChainCfg<C>::KS; ++ks) b[ks] = Wl[ks * 64];
+}
+template <int C>
+__device__ __forceinline__ void chain_mma(const char* sA, const uint4* b, int lane, f32x16_t& acc) {
+    const char* ap = sA + (lane & 31) * ChainCfg<C>::AROW + (lane >> 5) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < ChainCfg<C>::KS; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + ks * 32), __builtin_bit_cast(bf16x8_t, b[ks]), acc, 0, 0, 0);
+}
+
+template <int C>
+__global__ __launch_bounds__(ChainCfg<C>::THREADS) void naf_chain_kernel(const ChainP p) {
+    typedef ChainCfg<C> K;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * K::BM;
+    const int face = row0 / p.hw;                                  // 32 rows never straddle faces (hw % 32 == 0)
+    float* s_vec = reinterpret_cast<float*>(smem + K::S_OFF);
+    float* gb = reinterpret_cast<float*>(smem + K::GB_OFF);
+    float* yt = reinterpret_cast<float*>(smem + K::Y_OFF);
+    const int tile = wave;                                         // this wave's 32 output columns
+    const int col = tile * 32 + (lane & 31);
+    const bool full = row0 + K::BM <= p.M;
+
+    uint4 bw[K::KS], bw2[K::KS];
+    chain_load_b<C>(p.Wsca, tile, lane, bw);                       // SCA weights first
+    // ---- FiLM gain/bias of norm2 for this face/step into LDS ----
+    {
+        const int step = p.step_ptr ? *p.step_ptr : 0;
+        const float* f = p.film + (size_t)step * p.film_step_stride + (size_t)(p.face0 + face) * p.film_face_stride;
+        for (int k = tid; k < C; k += K::THREADS) { gb[k] = f[p.film_gain_off + k]; gb[C + k] = f[p.film_bias_off + k]; }
+    }
+    // ---- SCA: s = Wsca * pooled[face] + b on the MFMA (row 0 of the A tile holds the pooled vector) ----
+    {
+        const float* pv = p.pooled + (size_t)face * C;
+        uint4 a[K::KS];
+#pragma unroll
+        for (int ks = 0; ks < K::KS; ++ks) {
+            a[ks] = make_uint4(0, 0, 0, 0);
+            if ((lane & 31) == 0) {
+                const float* q = pv + ks * 16 + 8 * (lane >> 5);
+                const float4 v0 = *reinterpret_cast<const float4*>(q), v1 = *reinterpret_cast<const float4*>(q + 4);
+                a[ks] = make_uint4(pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w));
+            }
+        }
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < K::KS; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ks]), __builtin_bit_cast(bf16x8_t, bw[ks]), acc, 0, 0, 0);
+        if (lane < 32) s_vec[col] = acc[0] + p.bsca[col];          // C/D row 0 = reg 0 of lanes 0..31
+    }
+    chain_load_b<C>(p.W3, tile, lane, bw);                         // conv3 weights fly during the staging below
+    // residual x for this wave's tile (needed by the conv3 epilogue): request it now as well
+    float xr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        xr[i] = (full || row0 + rl < p.M) ? p.X[(size_t)(row0 + rl) * C + col] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- A1 = bf16(G * s): 32 rows x C, whole 128-byte lines ----
+    {
+        char* sA = smem + K::A1_OFF;
+        for (int u = tid; u < K::BM * (C / 8); u += K::THREADS) {
+            const int rl = u / (C / 8), kq = u - rl * (C / 8);
+            const int row = row0 + rl;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (full || row < p.M) {
+                x = *reinterpret_cast<const uint4*>(p.G + (size_t)row * C + kq * 8);
+                float v[8]; unpack8(x, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= s_vec[kq * 8 + i];
+                x = pack8(v);
+            }
+            *reinterpret_cast<uint4*>(sA + rl * K::AROW + kq * 16) = x;
+        }
+    }
+    __syncthreads();
+
+    // ---- conv3 -> y = x + beta * (acc + b3) into LDS ----
+    {
+        f32x16_t acc;
+        chain_mma<C>(smem + K::A1_OFF, bw, lane, acc);
+        chain_load_b<C>(p.W4, tile, lane, bw);                     // conv4 weights (both gate halves) for later
+        chain_load_b<C>(p.W4, tile + K::NT, lane, bw2);
+        const float bb = p.b3[col], be = p.beta[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            yt[rl * K::YROW + col] = xr[i] + (acc[i] + bb) * be;
+        }
+    }
+    __syncthreads();
+
+    // ---- LayerNorm + FiLM on y (statistics fp32 two-pass; the normalised value is the bf16 copy of y, as in
+    //      the unfused path) -> A2 ----
+    {
+        char* sA = smem + K::A2_OFF;
+        constexpr int PER = C / 64;                                  // values per lane per row
+        constexpr int RPW = K::BM / K::WAVES;                        // rows per wave
+        for (int rl = wave * RPW; rl < wave * RPW + RPW; ++rl) {
+            float v[PER];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { v[i] = yt[rl * K::YROW + lane + 64 * i]; sum += v[i]; }
+            const float mean = wave_sum(sum) * (1.0f / C);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q += d * d; }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + p.ln_eps);
+            const float nmr = -mean * rstd;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = lane + 64 * i;
+                const float yq = bf16_bits_to_f32(f32_to_bf16_bits(v[i]));
+                const float a = fmaf(fmaf(yq, rstd, nmr), gb[k], gb[C + k]);
+                *reinterpret_cast<unsigned short*>(sA + rl * K::AROW + k * 2) = f32_to_bf16_bits(a);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv4 (tile j and tile j + C/32) -> SimpleGate -> A3 (reuses the A1 region) ----
+    {
+        f32x16_t acc1, acc2;
+        chain_mma<C>(smem + K::A2_OFF, bw, lane, acc1);
+        chain_mma<C>(smem + K::A2_OFF, bw2, lane, acc2);
+        chain_load_b<C>(p.W5, tile, lane, bw);                     // conv5 weights
+        char* sA = smem + K::A1_OFF;
+        const float b1 = p.b4[col], b2 = p.b4[col + C];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            *reinterpret_cast<unsigned short*>(sA + rl * K::AROW + col * 2) = f32_to_bf16_bits((acc1[i] + b1) * (acc2[i] + b2));
+        }
+    }
+    __syncthreads();
+
+    // ---- conv5 -> x' = y + gamma * (acc + b5): fp32, bf16 copy, LayerNorm partials, optional HCA-gated copy ----
+    {
+        f32x16_t acc;
+        chain_mma<C>(smem + K::A1_OFF, bw, lane, acc);
+        const float bb = p.b5[col], ga = p.gamma[col];
+        float v[16], gat[16];
+        if (p.outg16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const bool ok = full || row < p.M;
+                const float a = (ok && p.add_src) ? p.add_src[(size_t)row * C + col] : 0.f;
+                gat[i] = ok ? 1.0f + p.gate_c[(size_t)face * C + col] + p.gate_s[row] : 0.f;   // gates are per launch (chain-local faces)
+                v[i] = a;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            const int row = row0 + rl;
+            const float add = p.outg16 ? v[i] : 0.f;
+            v[i] = yt[rl * K::YROW + col] + (acc[i] + bb) * ga;
+            if (full || row < p.M) {
+                p.Xout[(size_t)row * C + col] = v[i];
+                if (p.Xout16) p.Xout16[(size_t)row * C + col] = f32_to_bf16_bits(v[i]);
+                if (p.outg16) p.outg16[(size_t)row * C + col] = f32_to_bf16_bits((v[i] + add) * gat[i]);
+            } else {
+                v[i] = 0.f;
+            }
+        }
+        if (p.stats_out) {
+            float2 ms[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ms[i] = halfwave_mean_m2(v[i]);
+            if ((lane & 31) == kStatLane) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    if (full || row < p.M) p.stats_out[(size_t)row * (C / 32) + tile] = ms[i];
+                }
+            }
+        }
+    }
+}
+
+template <int C>
+inline hipError_t launch_chain(const ChainP& p, hipStream_t s) {
+    typedef ChainCfg<C> K;
+    if (K::SMEM > 65536) {
+        static bool granted = false;
+        if (!granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&naf_chain_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+            if (e != hipSuccess) return e;
+            granted = true;
+        }
+    }
+    hipLaunchKernelGGL((naf_chain_kernel<C>), dim3((p.M + K::BM - 1) / K::BM), dim3(K::THREADS), K::SMEM, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace hd

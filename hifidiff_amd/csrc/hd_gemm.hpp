@@ -77,7 +77,11 @@ struct GemmP {
     const float* dw_w;            // [N][9]
     const float* dw_b;            // [N]
     float* pooled;                // [faces][N/2]
+    unsigned short* pooled16;     // bf16 copy of pooled (A operand of the SCA GEMM), or NULL
     int side;                     // face side (hw = side*side)
+    // SCA epilogue (EpScaBF16): rows of this GEMM are faces; scale_G[(face*scale_hw + r)][col] *= s in place
+    unsigned short* scale_G;
+    int scale_hw;
 #ifdef HD_STAMPS
     unsigned long long* stamps;   // diagnostic build (tools/gemm_bench): [workgroup][8] s_memrealtime ticks (100 MHz)
 #endif
@@ -408,6 +412,27 @@ struct EpBiasF32 {
         v = activate(v + c.bias, p.act);
         reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
         if (p.out16) p.out16[(size_t)row * p.ldo + col] = f32_to_bf16_bits(v);
+        return v;
+    }
+};
+// SCA: s = acc + bias (fp32 out, rows = faces) and, in place, G[pixels of the face][col] <- bf16(G * s): the
+// product x * sca(x) of conditional_naf.py:119 with the same rounding as the scale loader, so conv3 reads G plainly.
+struct EpScaBF16 {
+    static constexpr bool kStats = false, kTile = false;
+    static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = 0.f; c.rscale = 1.f; return c; }
+    static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
+    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float, const ColC& c) {
+        v += c.bias;
+        reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
+        unsigned short* __restrict__ g = p.scale_G + (size_t)row * p.scale_hw * p.ldo + col;
+        const int hw = p.scale_hw;
+        for (int r0 = 0; r0 < hw; r0 += 8) {               // loads batched 8 deep so they overlap
+            unsigned short t[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (r0 + r < hw) ? g[(size_t)(r0 + r) * p.ldo] : (unsigned short)0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (r0 + r < hw) g[(size_t)(r0 + r) * p.ldo] = f32_to_bf16_bits(bf16_bits_to_f32(t[r]) * v);
+        }
         return v;
     }
 };
@@ -962,7 +987,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
             float sacc = 0.f;
             for (int r = 0; r < S; ++r) sacc += rs[(f * S + r) * 32 + j];
             const int face = row0 / HW + f;
-            if (face * HW < p.M && col < ncols) p.pooled[(size_t)face * C2 + col] = sacc / (float)HW;
+            if (face * HW < p.M && col < ncols) {
+                const float pm = sacc / (float)HW;
+                p.pooled[(size_t)face * C2 + col] = pm;
+                if (p.pooled16) p.pooled16[(size_t)face * C2 + col] = f32_to_bf16_bits(pm);
+            }
         }
     } else {
         // ================= element-wise epilogue, 32 lanes = one row of the tile =================

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/hifidiff_hip.h"
+#include "hd_chain.hpp"
 #include "hd_gemm.hpp"
 #include "hd_kernels.hpp"
 
@@ -56,7 +57,7 @@ struct ResConv { PackedW w; int cin, cout, k, stride, pad; };
 struct ResBlock { ResConv c1, c2, c3, ds; bool has_ds = false; };
 
 enum LdKind { LK_F32, LK_LN, LK_BF16, LK_BF16S, LK_CONV_F32, LK_CONV_F32G, LK_CONV_BF16 };
-enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE };
+enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE, EK_SCA };
 
 struct Op {
     std::string name;
@@ -66,7 +67,7 @@ struct Op {
     int out_bf16 = 0;
 };
 
-struct Level { int C, H, M; float *X, *Y, *T1, *pooled, *S; unsigned short *G, *Xb, *Yb, *Xg; float2 *sx, *sy; };
+struct Level { int C, H, M; float *X, *Y, *T1, *pooled, *S; unsigned short *G, *Xb, *Yb, *Xg, *pooled16; float2 *sx, *sy; };
 
 }  // namespace
 
@@ -380,6 +381,7 @@ hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStre
     if (lk == LK_BF16 && ek == EK_BIASBF16) return launch_tile<LdBF16Plain, EpBiasBF16, false>(p, mode, s);
     if (lk == LK_CONV_BF16 && ek == EK_BIASF32) return launch_tile<LdConv<true, false>, EpBiasF32, false>(p, mode, s);
     if (lk == LK_BF16 && ek == EK_PIXSHUF) return launch_tile<LdBF16Plain, EpPixShufF32, false>(p, mode, s);
+    if (lk == LK_BF16 && ek == EK_SCA) return launch_tile<LdBF16Plain, EpScaBF16, false>(p, mode, s);
     if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, mode, s);
     return hipErrorInvalidValue;
 }
@@ -457,7 +459,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         GemmP p = base_gemm(bw.conv1, M);
         p.A = lv.Xb; p.lda = C; film_fields(p, 0);
         p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
-        p.out = lv.G; p.ldo = C; p.dw_w = bw.dw_w; p.dw_b = bw.dw_b; p.pooled = lv.pooled; p.side = lv.H;
+        p.out = lv.G; p.ldo = C; p.dw_w = bw.dw_w; p.dw_b = bw.dw_b; p.pooled = lv.pooled; p.pooled16 = lv.pooled16; p.side = lv.H;
         add_gemm(c, prog, bw.name + ".conv2_gate_pool", p, LK_LN, EK_DWGATE);
     } else {
         {   // LN1 + FiLM -> conv1 (+bias) -> T1
@@ -478,17 +480,66 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
             prog.back().out = G; prog.back().out_elems = (size_t)M * C; prog.back().out_bf16 = 1;
         }
     }
-    {   // SCA 1x1 conv on the pooled vector
-        GemmP p = base_gemm(bw.sca, M / HW);
-        p.A = lv.pooled; p.lda = C; p.out = lv.S; p.ldo = C;
-        add_gemm(c, prog, bw.name + ".sca", p, LK_F32, EK_BIASF32);
+    static const bool no_chain = getenv("HD_NO_CHAIN") != nullptr;
+    if ((C == 128 || C == 256) && HW % 32 == 0 && dwgate_ok(HW) && !no_fuse && !no_chain) {
+        // levels 0/1: sca -> conv3 -> residual -> LN+FiLM -> conv4 -> gate -> conv5 -> residual in ONE launch (hd_chain.hpp)
+        ChainP q{};
+        q.M = M; q.hw = HW; q.face0 = c->ch->face0;
+        q.G = lv.G; q.pooled = lv.pooled; q.X = lv.X;
+        q.Wsca = bw.sca.w; q.W3 = bw.conv3.w; q.W4 = bw.conv4.w; q.W5 = bw.conv5.w;
+        q.bsca = bw.sca.bias; q.b3 = bw.conv3.bias; q.b4 = bw.conv4.bias; q.b5 = bw.conv5.bias; q.beta = bw.beta; q.gamma = bw.gamma;
+        q.film = static_film; q.film_bias_off = bw.film_off + 2 * C; q.film_gain_off = bw.film_off + 3 * C; q.ln_eps = 1e-6f;
+        q.Xout = lv.X; q.Xout16 = lv.Xb; q.stats_out = lv.sx;
+        if (gate) { q.outg16 = lv.Xg; q.gate_c = gate->gate_c; q.gate_s = gate->gate_s; q.add_src = gate->add; q.stats_out = nullptr; q.Xout16 = nullptr; }
+        Chain* chp = c->ch;
+        const bool big = (C == 256);
+        Op op;
+        op.name = bw.name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)M * C; op.out_bf16 = 0;
+        op.run = [c, chp, q, big](hipStream_t s) mutable -> hipError_t {
+            ChainP r = q;
+            if (r.film == nullptr) {                      // denoiser: FiLM rows live in the (re-allocatable) table
+                r.film = c->film_table; r.film_face_stride = c->film_face_stride; r.film_step_stride = c->film_step_stride;
+                r.step_ptr = &chp->step_state->step;
+            }
+            return big ? launch_chain<256>(r, s) : launch_chain<128>(r, s);
+        };
+        prog.push_back(op);
+        *x_np = C / 32; *x_cnt = 32;
+        return;
     }
-    {   // (G * S) -> conv3 -> y = x + beta * (.)
-        GemmP p = base_gemm(bw.conv3, M);
-        p.A = lv.G; p.lda = C; p.hw = HW; p.rowscale = lv.S;
-        p.out = lv.Y; p.ldo = C; p.resid = lv.X; p.ldr = C; p.rscale = bw.beta;
-        p.stats_out = lv.sy; p.out16 = lv.Yb;
-        add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16S, EK_RESID);
+    const bool prescale = dwgate_ok(HW) && !no_fuse && HW <= 4;      // fused conv1 wrote pooled16; few pixels per face (more rows serialise the epilogue)
+    if (prescale) {
+        {   // SCA on the bf16 pooled vector; its epilogue also scales G in place: G <- bf16(G * s)
+            GemmP p = base_gemm(bw.sca, M / HW);
+            p.A = lv.pooled16; p.lda = C; p.out = lv.S; p.ldo = C; p.scale_G = lv.G; p.scale_hw = HW;
+            add_gemm(c, prog, bw.name + ".sca", p, LK_BF16, EK_SCA);
+        }
+        {   // conv3 on the pre-scaled G -> y = x + beta * (.)
+            GemmP p = base_gemm(bw.conv3, M);
+            p.A = lv.G; p.lda = C;
+            p.out = lv.Y; p.ldo = C; p.resid = lv.X; p.ldr = C; p.rscale = bw.beta;
+            p.stats_out = lv.sy; p.out16 = lv.Yb;
+            add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16, EK_RESID);
+        }
+    } else {
+        {   // SCA 1x1 conv on the pooled vector
+            GemmP p = base_gemm(bw.sca, M / HW);
+            p.out = lv.S; p.ldo = C;
+            if (dwgate_ok(HW) && !no_fuse) {            // fused conv1 left a bf16 pooled vector: half the A bytes
+                p.A = lv.pooled16; p.lda = C; p.scale_G = lv.G; p.scale_hw = 0;
+                add_gemm(c, prog, bw.name + ".sca", p, LK_BF16, EK_SCA);
+            } else {
+                p.A = lv.pooled; p.lda = C;
+                add_gemm(c, prog, bw.name + ".sca", p, LK_F32, EK_BIASF32);
+            }
+        }
+        {   // (G * S) -> conv3 -> y = x + beta * (.)
+            GemmP p = base_gemm(bw.conv3, M);
+            p.A = lv.G; p.lda = C; p.hw = HW; p.rowscale = lv.S;
+            p.out = lv.Y; p.ldo = C; p.resid = lv.X; p.ldr = C; p.rscale = bw.beta;
+            p.stats_out = lv.sy; p.out16 = lv.Yb;
+            add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16S, EK_RESID);
+        }
     }
     {   // LN2 + FiLM -> conv4 -> SimpleGate -> G2 (bf16, reuses G)
         GemmP p = base_gemm(bw.conv4, M);
@@ -574,6 +625,7 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
         rc |= dev_alloc(c, &v.G, mc); rc |= dev_alloc(c, &v.pooled, (size_t)B * v.C); rc |= dev_alloc(c, &v.S, (size_t)B * v.C);
         rc |= dev_alloc(c, &v.sx, (size_t)v.M * (v.C / 32)); rc |= dev_alloc(c, &v.sy, (size_t)v.M * (v.C / 32));
         rc |= dev_alloc(c, &v.Xb, mc); rc |= dev_alloc(c, &v.Yb, mc); rc |= dev_alloc(c, &v.Xg, mc);
+        rc |= dev_alloc(c, &v.pooled16, (size_t)B * v.C);
         const int pi = 4 - l;                            // prior index: coarsest first
         rc |= dev_alloc(c, &ch.prior[pi], mc); rc |= dev_alloc(c, &ch.gate_c[pi], (size_t)B * v.C);
         rc |= dev_alloc(c, &ch.gate_s[pi], (size_t)v.M);
@@ -606,12 +658,12 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
 
 int build_denoiser_program(hd_ctx* c);
 
-// Cut the batch into chains.  Default: 2 chains once each still holds >= 16 faces (the GEMM tiles are 32
-// rows, so smaller chains waste MFMA rows); HD_CHAINS overrides.
+// Cut the batch into chains (HD_CHAINS, default 1).  Two streams of these kernels do overlap (1.6x in
+// tools/gemm_bench), but halving M does not make a kernel cheaper, so splitting the batch is not a win.
 int alloc_workspace(hd_ctx* c, int B) {
     if (B == c->B) return HD_OK;
     if (c->B != 0) HD_FAIL(c, HD_ERR_INVALID, "batch size change (%d -> %d) needs a new context", c->B, B);
-    int n = (B >= 32) ? 2 : 1;
+    int n = 1;                                            // measured: per-kernel cost barely depends on M, so more chains only add launches
     if (const char* e = getenv("HD_CHAINS")) n = atoi(e);
     if (n < 1) n = 1;
     if (n > 8) n = 8;
