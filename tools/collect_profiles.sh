@@ -1,0 +1,43 @@
+#!/bin/bash
+# Collects the per-round evidence bench.py's roofline block refers to.  Run on the GPU box from the repo root:
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r01'
+# Outputs land in gpurun_out/<round>/ ; copy the summaries into profiles/ afterwards (see the end of this file).
+set -e -o pipefail
+R=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$R
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+
+# 1. kernel trace + stats of the same command at 100 diffusion steps (1000 steps = 157k dispatches per pass)
+cd /tmp
+HD_DUMP_OPS=$OUT/ops.txt timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
+    python "$ROOT/bench.py" --steps 1 --warmup 0 --diffusion-steps 100 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+cd "$ROOT"
+TRACE=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
+STATS=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
+python tools/prof_summary.py "$TRACE" "$OUT/ops.txt" > "$OUT/kernel_trace_summary.txt"
+cp "$STATS" "$OUT/kernel_stats.csv"
+rm -f "$TRACE"                                     # tens of MB; the summary and stats are what is kept
+grep "steps x" "$OUT/kernel_trace_summary.txt"
+
+# 2. HBM traffic: one counter per pass, two lengths, difference isolates the replay loop
+for C in FETCH_SIZE WRITE_SIZE; do
+  for N in 10 30; do
+    cd /tmp
+    timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_$N" -- \
+        python "$ROOT/bench.py" --steps 1 --warmup 0 --diffusion-steps $N --no-cpu-baseline > "$OUT/pmc_${C}_$N.log" 2>&1
+    cd "$ROOT"
+  done
+  A=$(find "$OUT/pmc_${C}_10" -name "*counter_collection.csv" | head -1)
+  B=$(find "$OUT/pmc_${C}_30" -name "*counter_collection.csv" | head -1)
+  python tools/pmc_traffic.py "$A" 10 "$B" 30 $C "$OUT/traffic.json" | tee -a "$OUT/traffic.txt"
+  rm -rf "$OUT/pmc_${C}_10" "$OUT/pmc_${C}_30"
+done
+cp "$OUT/traffic.json" "$ROOT/profiles/${R}_traffic.json"      # bench.py reads profiles/<round>_traffic.json
+
+# 3. the headline bench line (includes the cpu_baseline leg)
+timeout -k 10 600 python bench.py --steps 3 --warmup 1 > "$OUT/bench_1gpu.json.log" 2> "$OUT/bench_1gpu.stderr"
+tail -c 600 "$OUT/bench_1gpu.json.log"; echo
+
+echo done
