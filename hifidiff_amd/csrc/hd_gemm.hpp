@@ -174,6 +174,9 @@ struct LdF32Plain {
     static constexpr bool kGainBiasLds = false, kSplit = true;
     struct St { const float* rowp; bool valid; };
     struct Raw { F8 x; };
+    struct Pre {};
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
@@ -199,51 +202,135 @@ struct LdF32LN {
     static constexpr bool kGainBiasLds = true, kSplit = false;
     struct St { const unsigned short* rowp; const float* gain; const float* bias; const float* gbl; float mu, rstd; bool valid; };   // mu holds -mean*rstd
     struct Raw { uint4 x; };
-    // (1) merge the producer's per-tile (mean, M2) partials of each row into (mean, rstd) in LDS: 4 threads
+    // block prologue in two halves so that its (small) loads can be issued before the weight / A streams and
+    // consumed while those are still arriving (vector loads return in issue order):
+    // (1) merge the producer's per-tile (mean, M2) partials of each row into (mean, rstd) in LDS: TPR threads
     //     per row, Chan's update (Chan, Golub, LeVeque 1979), fixed order -> deterministic;
     // (2) when every row shares one FiLM row (sampling: same t for all faces) copy gain/bias[K] to LDS so
     //     finish() never waits on global memory.
-    template <int BM, int THREADS> static __device__ void block_init(const GemmP& p, int row0, char* stats, float* gb, int tid) {
-        float2* st = reinterpret_cast<float2*>(stats);
-        if (gb && p.film_face_stride == 0) {
-            const int step = p.step_ptr ? *p.step_ptr : 0;
-            const float* f = p.film + (size_t)step * p.film_step_stride;
-            for (int k = tid * 4; k < p.K; k += THREADS * 4) {
-                *reinterpret_cast<float4*>(gb + k) = *reinterpret_cast<const float4*>(f + p.film_gain_off + k);
-                *reinterpret_cast<float4*>(gb + p.Kp + k) = *reinterpret_cast<const float4*>(f + p.film_bias_off + k);
+    static constexpr int kPP = 4;                                       // partials held per thread
+    struct Pre { float2 s[kPP]; float4 g[2], b[2]; };
+    template <int BM, int THREADS> static constexpr int tpr() { return THREADS / BM >= 16 ? 16 : (THREADS / BM >= 1 ? THREADS / BM : 1); }
+    template <int BM, int THREADS> static __device__ __forceinline__ bool fast(const GemmP& p) {
+        return p.stats_np <= kPP * tpr<BM, THREADS>() && BM * tpr<BM, THREADS>() <= THREADS;
+    }
+    static __device__ __forceinline__ const float* film_row(const GemmP& p) {
+        const int step = p.step_ptr ? *p.step_ptr : 0;
+        return p.film + (size_t)step * p.film_step_stride;
+    }
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP& p, int row0, float* gb, int tid, Pre& pre) {
+        constexpr int TPR = tpr<BM, THREADS>();
+        if (fast<BM, THREADS>(p)) {
+            const int rl = tid / TPR, part = tid % TPR, row = row0 + rl;
+            const bool rv = rl < BM && row < p.M;
+            const float2* sp = p.stats_in + (size_t)(rv ? row : 0) * p.stats_np;
+#pragma unroll
+            for (int i = 0; i < kPP; ++i) {
+                const int j = part + i * TPR;
+                pre.s[i] = (rv && j < p.stats_np) ? sp[j] : make_float2(0.f, -1.f);     // M2 < 0 marks "no partial"
             }
         }
-        for (int base = 0; base < BM; base += THREADS / 4) {
-            const int rl = base + (tid >> 2), part = tid & 3;
-            const int row = row0 + rl;
+        if (gb && p.film_face_stride == 0) {
+            const float* f = film_row(p);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = (tid + i * THREADS) * 4;
+                if (k < p.K) {
+                    pre.g[i] = *reinterpret_cast<const float4*>(f + p.film_gain_off + k);
+                    pre.b[i] = *reinterpret_cast<const float4*>(f + p.film_bias_off + k);
+                }
+            }
+        }
+    }
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP& p, int row0, char* stats, float* gb, int tid, const Pre& pre) {
+        constexpr int TPR = tpr<BM, THREADS>();
+        float2* st = reinterpret_cast<float2*>(stats);
+        if (gb && p.film_face_stride == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = (tid + i * THREADS) * 4;
+                if (k < p.K) {
+                    *reinterpret_cast<float4*>(gb + k) = pre.g[i];
+                    *reinterpret_cast<float4*>(gb + p.Kp + k) = pre.b[i];
+                }
+            }
+            if (p.K > THREADS * 8) {                                    // longer rows than two passes cover
+                const float* f = film_row(p);
+                for (int k = (tid + 2 * THREADS) * 4; k < p.K; k += THREADS * 4) {
+                    *reinterpret_cast<float4*>(gb + k) = *reinterpret_cast<const float4*>(f + p.film_gain_off + k);
+                    *reinterpret_cast<float4*>(gb + p.Kp + k) = *reinterpret_cast<const float4*>(f + p.film_bias_off + k);
+                }
+            }
+        }
+        if (fast<BM, THREADS>(p)) {
+            const int rl = tid / TPR, part = tid % TPR;
+            const float cnt = (float)p.stats_cnt;
             float n = 0.f, mean = 0.f, m2 = 0.f;
-            if (rl < BM && row < p.M) {
-                const float2* sp = p.stats_in + (size_t)row * p.stats_np;
-                const float cnt = (float)p.stats_cnt;
-                for (int i = part; i < p.stats_np; i += 4) {
-                    const float2 v = sp[i];
-                    const float d = v.x - mean, nn = n + cnt;
+#pragma unroll
+            for (int i = 0; i < kPP; ++i) {
+                if (pre.s[i].y >= 0.f) {
+                    const float d = pre.s[i].x - mean, nn = n + cnt;
                     mean += d * (cnt / nn);
-                    m2 += v.y + d * d * (n * cnt / nn);
+                    m2 += pre.s[i].y + d * d * (n * cnt / nn);
                     n = nn;
                 }
             }
 #pragma unroll
-            for (int o = 1; o < 4; o <<= 1) {                       // butterfly over the quad: lane ^ 1, lane ^ 2
-                const float n2 = (o == 1) ? dpp_mov<0xB1>(n) : dpp_mov<0x4E>(n);
-                const float mean2 = (o == 1) ? dpp_mov<0xB1>(mean) : dpp_mov<0x4E>(mean);
-                const float m22 = (o == 1) ? dpp_mov<0xB1>(m2) : dpp_mov<0x4E>(m2);
-                const float nn = n + n2;
+            for (int o = 1; o < TPR; o <<= 1) {      // butterfly: lane^1, lane^2, half-row mirror, row mirror
+                const float n2 = o == 1 ? dpp_mov<0xB1>(n) : o == 2 ? dpp_mov<0x4E>(n) : o == 4 ? dpp_mov<0x141>(n) : dpp_mov<0x140>(n);
+                const float mean2 = o == 1 ? dpp_mov<0xB1>(mean) : o == 2 ? dpp_mov<0x4E>(mean) : o == 4 ? dpp_mov<0x141>(mean) : dpp_mov<0x140>(mean);
+                const float m22 = o == 1 ? dpp_mov<0xB1>(m2) : o == 2 ? dpp_mov<0x4E>(m2) : o == 4 ? dpp_mov<0x141>(m2) : dpp_mov<0x140>(m2);
+                // the pair (lower lane group, upper lane group) is always merged in that order
+                const bool hi = (part & o) != 0;
+                const float na = hi ? n2 : n, nb = hi ? n : n2;
+                const float ma = hi ? mean2 : mean, mb = hi ? mean : mean2;
+                const float nn = na + nb;
                 if (nn > 0.f) {
-                    const float d = mean2 - mean;
-                    m2 = m2 + m22 + d * d * (n * n2 / nn);
-                    mean = mean + d * (n2 / nn);
+                    const float d = mb - ma;
+                    m2 = m2 + m22 + d * d * (na * nb / nn);
+                    mean = ma + d * (nb / nn);
                     n = nn;
                 }
             }
             if (part == 0 && rl < BM) st[rl] = make_float2(mean, n > 0.f ? 1.0f / sqrtf(m2 / n + p.ln_eps) : 0.f);
+        } else {
+            for (int base = 0; base < BM; base += THREADS / 4) {
+                const int rl = base + (tid >> 2), part = tid & 3;
+                const int row = row0 + rl;
+                float n = 0.f, mean = 0.f, m2 = 0.f;
+                if (rl < BM && row < p.M) {
+                    const float2* sp = p.stats_in + (size_t)row * p.stats_np;
+                    const float cnt = (float)p.stats_cnt;
+                    for (int i = part; i < p.stats_np; i += 4) {
+                        const float2 v = sp[i];
+                        const float d = v.x - mean, nn = n + cnt;
+                        mean += d * (cnt / nn);
+                        m2 += v.y + d * d * (n * cnt / nn);
+                        n = nn;
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < 4; o <<= 1) {                       // butterfly over the quad: lane ^ 1, lane ^ 2
+                    const float n2 = (o == 1) ? dpp_mov<0xB1>(n) : dpp_mov<0x4E>(n);
+                    const float mean2 = (o == 1) ? dpp_mov<0xB1>(mean) : dpp_mov<0x4E>(mean);
+                    const float m22 = (o == 1) ? dpp_mov<0xB1>(m2) : dpp_mov<0x4E>(m2);
+                    const float nn = n + n2;
+                    if (nn > 0.f) {
+                        const float d = mean2 - mean;
+                        m2 = m2 + m22 + d * d * (n * n2 / nn);
+                        mean = mean + d * (n2 / nn);
+                        n = nn;
+                    }
+                }
+                if (part == 0 && rl < BM) st[rl] = make_float2(mean, n > 0.f ? 1.0f / sqrtf(m2 / n + p.ln_eps) : 0.f);
+            }
         }
         __syncthreads();
+    }
+    template <int BM, int THREADS> static __device__ void block_init(const GemmP& p, int row0, char* stats, float* gb, int tid) {
+        Pre pre;
+        block_issue<BM, THREADS>(p, row0, gb, tid, pre);
+        block_finish<BM, THREADS>(p, row0, stats, gb, tid, pre);
     }
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int row_local, const char* stats, const float* gb) {
         st.valid = row < p.M;
@@ -283,6 +370,9 @@ struct LdBF16Plain {
     static constexpr bool kGainBiasLds = false, kSplit = false;
     struct St { const unsigned short* rowp; bool valid; };
     struct Raw { uint4 x; };
+    struct Pre {};
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
@@ -300,6 +390,9 @@ struct LdBF16Scale {
     static constexpr bool kGainBiasLds = false, kSplit = false;
     struct St { const unsigned short* rowp; const float* srow; bool valid; };
     struct Raw { uint4 x; F8 s; };
+    struct Pre {};
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
@@ -332,6 +425,9 @@ struct LdConv {
     static constexpr bool kGainBiasLds = false, kSplit = !SRC_BF16;
     struct St { int b, iy0, ix0; bool valid; };
     struct Raw { float4 x[2]; float4 add[2]; float4 gc[2]; float gs[2]; uint4 xb; bool inb[2]; };
+    struct Pre {};
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
+    template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
@@ -706,11 +802,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
 }
 
 // ----------------------------------------------------------------------------------- skinny kernel
-template <int WM_, int WK_, int MT_, bool PAIR_, int D_>
+// HALF: 16-row workgroup tiles (WM = MT = 1 only): at M = 64 this doubles the workgroups (4 row groups instead
+// of 2) so all 256 CUs pull weights; rows 16..31 of the MFMA tile stay zero in LDS.
+template <int WM_, int WK_, int MT_, bool PAIR_, int D_, bool HALF_ = false>
 struct SkinnyCfg {
     static constexpr int WM = WM_, WK = WK_, MT = MT_, D = D_;
-    static constexpr int WAVES = WM * WK, THREADS = 64 * WAVES, BM = WM * MT * 32, TNT = PAIR_ ? 2 : 1;
-    static constexpr int UN = MT * 4;                            // (row, 8 k) units per lane per chunk
+    static constexpr bool HALF = HALF_;
+    static_assert(!HALF_ || (WM_ == 1 && MT_ == 1), "HALF tiles are single-row-tile workgroups");
+    static constexpr int WROWS = HALF_ ? 16 : MT_ * 32;          // rows of one wave's sub-tile that hold data
+    static constexpr int WAVES = WM * WK, THREADS = 64 * WAVES, BM = WM * WROWS, TNT = PAIR_ ? 2 : 1;
+    static constexpr int UN = WROWS / 8;                         // (row, 8 k) units per lane per chunk
     static constexpr int A_WAVE = MT * 32 * LDS_ROW;             // private staging tile of one wave
     static constexpr int RED = WK * BM * 32 * TNT * 4;           // [wk][tn][row][32] partial tiles (aliases staging)
     static constexpr int STAGE = (WAVES * A_WAVE > RED) ? WAVES * A_WAVE : RED;
@@ -842,11 +943,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
 #define HD_SK_LOAD_B(slot, chunk)                                                                      \
     _Pragma("unroll") for (int ss = 0; ss < 4; ++ss) _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn) \
         bq[slot][ss][tn] = ((chunk) < c_end) ? Wl[((size_t)tile[tn] * ksteps_total + (chunk) * 4 + ss) * 64] : make_uint4(0, 0, 0, 0);
-    // weights first: they do not depend on anything this kernel has to wait for
+    // the block prologue's small loads (LayerNorm partials, FiLM row) go out first, then the weights: neither
+    // depends on anything this kernel computes, and loads return in issue order
+    float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + C::GB_OFF) : nullptr;
+    typename LD::Pre pre;
+    LD::template block_issue<C::BM, C::THREADS>(p, row0, gb, tid, pre);
 #pragma unroll
     for (int d = 0; d < D; ++d) { HD_SK_LOAD_B(d, c0 + d); }
 
-    float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + C::GB_OFF) : nullptr;
     typename LD::St st[UN];
     int u_off[UN];
     const int kq = lane & 7;
@@ -854,8 +958,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     // depend on the LayerNorm statistics, only finish() does
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-        const int rw = (lane >> 3) + 8 * u;                      // row inside the wave's MT*32-row sub-tile
-        const int rl = wm * MT * 32 + rw;
+        const int rw = (lane >> 3) + 8 * u;                      // row inside the wave's sub-tile
+        const int rl = wm * C::WROWS + rw;
         u_off[u] = rw * LDS_ROW;
         LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
     }
@@ -864,11 +968,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         LD::fetch(p, st[u], ((chunk) < c_end) ? (chunk) * BK : p.Kp, kq, aq[slot][u]);
 #pragma unroll
     for (int d = 0; d < D; ++d) { HD_SK_FETCH_A(d, c0 + d); }
-    LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
+    LD::template block_finish<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid, pre);
     if (LD::kGainBiasLds) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int rl = wm * MT * 32 + (lane >> 3) + 8 * u;
+            const int rl = wm * C::WROWS + (lane >> 3) + 8 * u;
             LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
         }
     }
@@ -876,6 +980,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
 
     char* sA = smem + wave * C::A_WAVE;
     const int a_lane_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
+    if constexpr (C::HALF) {                                   // rows 16..31 are never staged: keep them zero
+        for (int i = lane; i < 16 * LDS_ROW / 16; i += 64) reinterpret_cast<uint4*>(sA + 16 * LDS_ROW)[i] = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
     for (int cb = c0; cb < c_end; cb += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -919,7 +1027,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
         for (int tn = 0; tn < TNT; ++tn)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < (C::HALF ? 8 : 16); ++i) {
                 const int r = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 red[wk * TILE_F + (tn * C::BM + r) * 32 + (lane & 31)] = acc[mt][tn][i];
             }
@@ -1064,6 +1172,15 @@ template <int WM, int MT, bool PAIR, class LD, class EP>
 inline hipError_t launch_skinny_auto(const GemmP& p, hipStream_t s) {
     constexpr int D = ChunkDepth<MT, PAIR, LD>::D;
     const int chunks = p.Kp / 64;
+    if constexpr (WM == 1 && MT == 1) {
+        // few rows, many columns: 16-row tiles double the workgroups so that every CU streams weights
+        static const bool no_half = getenv("HD_NO_HALF") != nullptr;
+        const int tiles = (PAIR ? p.N / 2 : p.N) / 32;
+        static const int half_m = getenv("HD_HALF_M") ? atoi(getenv("HD_HALF_M")) : 64;
+        static const int half_wg = getenv("HD_HALF_WG") ? atoi(getenv("HD_HALF_WG")) : 256;
+        if (!no_half && p.M <= half_m && p.M % 16 == 0 && ((p.M + 31) / 32) * tiles < half_wg && chunks >= 16 && chunks % 8 == 0)
+            return launch_skinny<SkinnyCfg<1, 8, 1, PAIR, D, true>, LD, EP>(p, s);
+    }
     if constexpr (WM <= 1) if (chunks >= 16 && chunks % 8 == 0) return launch_skinny<SkinnyCfg<WM, 8, MT, PAIR, D>, LD, EP>(p, s);
     if constexpr (WM <= 2) if (chunks >= 8 && chunks % 4 == 0) return launch_skinny<SkinnyCfg<WM, 4, MT, PAIR, D>, LD, EP>(p, s);
     if constexpr (WM <= 4) if (chunks >= 4 && chunks % 2 == 0) return launch_skinny<SkinnyCfg<WM, 2, MT, PAIR, D>, LD, EP>(p, s);

@@ -11,7 +11,7 @@ namespace hd {
 // Device-resident loop state read by the captured per-step graph (so one graph serves every step).
 struct StepState {
     int step;                 // index into the schedule; incremented by the first kernel of a step
-    int pad;
+    int n_steps;              // length of the schedule (0: single evaluation)
     const float* noise;       // [n_steps][n_elems] or NULL -> Philox
     unsigned long long seed;
 };
@@ -314,10 +314,22 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 // x/eps point at this chain's faces; elem0 / n_total place them inside the whole batch so that the noise
 // tensor and the Philox counters are indexed exactly as for an unsplit batch.
 __global__ void sched_step_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ coef,
-                                  const StepState* __restrict__ st, int n, int elem0, int n_total) {
+                                  const StepState* __restrict__ st, int n, int elem0, int n_total,
+                                  const float* __restrict__ film_table, float* __restrict__ film_cur, int film_total) {
+    const int step = st->step;
+    const int nb = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+    if ((int)blockIdx.x >= nb) {
+        // trailing workgroups: stage the NEXT step's FiLM row at a fixed address, so that no LayerNorm loader of
+        // the next replay has to chase the step index through memory before it can fetch its gain/bias
+        if (step + 1 >= st->n_steps) return;
+        const float4* src = reinterpret_cast<const float4*>(film_table + (size_t)(step + 1) * film_total);
+        float4* dst = reinterpret_cast<float4*>(film_cur);
+        const int i = ((int)blockIdx.x - nb) * (int)blockDim.x + (int)threadIdx.x;
+        if (i < film_total / 4) dst[i] = src[i];
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int step = st->step;
     const float* c = coef + (size_t)step * 7;
     const float xv = x[i], e = eps[i];
     float x0 = (xv - c[0] * e) / c[1];

@@ -84,6 +84,7 @@ struct Chain {
     std::vector<Op> program;                 // one denoiser evaluation (lat -> eps) of this chain's faces
     std::vector<Op> prep_program;            // the most recent conditioning prologue
     StepState* step_state = nullptr;         // device-resident loop state of this chain
+    float* film_cur = nullptr;               // FiLM row of the step being evaluated (sampling loop; see sched_step_kernel)
     hipStream_t stream = nullptr;            // the chain's own queue for the sampling loop
     hipEvent_t done = nullptr;
     hipGraphExec_t graph_exec = nullptr;     // program + scheduler update of this chain, replayed per step
@@ -123,6 +124,7 @@ struct hd_ctx {
     float *t_dev = nullptr, *temb_a = nullptr, *temb_b = nullptr, *temb_c = nullptr, *film_table = nullptr;
     int film_rows_cap = 0;
     int film_face_stride = 0, film_step_stride = 0;
+    bool film_from_cur = false;               // sampling loop: LayerNorm loaders read Chain::film_cur
     float* coef_dev = nullptr;
     int coef_cap = 0;
     int advance = 0;
@@ -427,10 +429,10 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
     op.run = [c, chp, p, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
                         if (film && p.film == nullptr) {          // denoiser FiLM rows live in the (re-allocatable) table
                             GemmP q = p;
-                            q.film = c->film_table;
+                            q.film = c->film_from_cur ? chp->film_cur : c->film_table;
                             q.film_face_stride = c->film_face_stride;
-                            q.film_step_stride = c->film_step_stride;
-                            q.step_ptr = &chp->step_state->step;
+                            q.film_step_stride = 0;
+                            q.step_ptr = nullptr;
                             return dispatch_gemm(q, lk, ek, t128, s);
                         }
                         return dispatch_gemm(p, lk, ek, t128, s);
@@ -498,8 +500,8 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         op.run = [c, chp, q, big](hipStream_t s) mutable -> hipError_t {
             ChainP r = q;
             if (r.film == nullptr) {                      // denoiser: FiLM rows live in the (re-allocatable) table
-                r.film = c->film_table; r.film_face_stride = c->film_face_stride; r.film_step_stride = c->film_step_stride;
-                r.step_ptr = &chp->step_state->step;
+                r.film = c->film_from_cur ? chp->film_cur : c->film_table; r.film_face_stride = c->film_face_stride; r.film_step_stride = 0;
+                r.step_ptr = nullptr;
             }
             return big ? launch_chain<256>(r, s) : launch_chain<128>(r, s);
         };
@@ -649,6 +651,7 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
     for (int i = 0; i < 4; ++i) rc |= dev_alloc(c, &ch.res_buf[i], rmax);
     rc |= dev_alloc(c, &ch.face8, (size_t)B * 128 * 128);
     rc |= dev_alloc(c, &ch.step_state, 1);
+    rc |= dev_alloc(c, &ch.film_cur, (size_t)c->film_total);
     if (rc) return rc;
     HIPCHECK(c, hipMemset(ch.step_state, 0, sizeof(StepState)));
     HIPCHECK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
@@ -1284,6 +1287,7 @@ int hd_eps(hd_ctx* c, const float* x, const float* timesteps, int n_t, float* ep
     rc = compute_film(c, timesteps, n_t, s);
     if (rc) return rc;
     c->film_step_stride = 0;
+    c->film_from_cur = false;
     c->film_face_stride = (n_t == 1) ? 0 : c->film_total;
     c->advance = 0;
     for (auto& ch : c->chains) {
@@ -1316,7 +1320,7 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
     HIPCHECK(c, hipMemcpyAsync(c->coef_dev, sched->coef, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHECK(c, hipMemcpyAsync(c->t_dev, sched->timesteps, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
     StepState st{};
-    st.step = -1; st.noise = noise; st.seed = seed;
+    st.step = -1; st.n_steps = n; st.noise = noise; st.seed = seed;
     for (auto& ch : c->chains) HIPCHECK(c, hipMemcpyAsync(ch.step_state, &st, sizeof(st), hipMemcpyHostToDevice, s));
     HIPCHECK(c, hipStreamSynchronize(s));                 // the host buffers above are caller/stack memory
     HIPCHECK(c, hipMemcpyAsync(c->lat, x_inout, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1324,7 +1328,10 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
     if (rc) return rc;
     c->film_step_stride = c->film_total;
     c->film_face_stride = 0;
+    c->film_from_cur = true;
     c->advance = 1;
+    for (auto& ch : c->chains)                          // step 0's row; sched_step stages row i+1 during step i
+        HIPCHECK(c, hipMemcpyAsync(ch.film_cur, c->film_table, (size_t)c->film_total * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!c->graphs_valid || c->graph_film != c->film_table || c->graph_B != c->B) {
         // One graph per chain: its launch program + its scheduler update.  Faces never interact, so the
         // chains are independent over the whole loop and each graph is replayed on the chain's own stream.
@@ -1336,8 +1343,9 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
                 for (size_t k = 0; k < ch.program.size() && e == hipSuccess; ++k) e = ch.program[k].run(ch.stream);
                 if (e == hipSuccess) {
                     const int nel = (int)(ch.B * per_face);
-                    hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ch.stream, ch.lat, ch.eps, c->coef_dev,
-                                       ch.step_state, nel, (int)(ch.face0 * per_face), (int)nlat);
+                    const unsigned nb_sched = (unsigned)((nel + 255) / 256), nb_film = (unsigned)((c->film_total / 4 + 255) / 256);
+                    hipLaunchKernelGGL(sched_step_kernel, dim3(nb_sched + nb_film), dim3(256), 0, ch.stream, ch.lat, ch.eps, c->coef_dev,
+                                       ch.step_state, nel, (int)(ch.face0 * per_face), (int)nlat, c->film_table, ch.film_cur, c->film_total);
                     e = hipGetLastError();
                 }
                 hipError_t e2 = hipStreamEndCapture(ch.stream, &graph);

@@ -82,14 +82,15 @@ int main(int argc, char** argv) {
     void* Ab; CK(hipMalloc(&Ab, (size_t)M * K * 2)); hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, (unsigned*)Ab, (size_t)M * K / 2, 99u);
     CK(hipMalloc(&b.out, (size_t)M * N * 4)); CK(hipMalloc(&b.outb, (size_t)M * N * 2));
     CK(hipMalloc(&b.bias, N * 4)); CK(hipMalloc(&b.rscale, N * 4)); CK(hipMalloc(&b.resid, (size_t)M * N * 4));
-    CK(hipMalloc(&b.film, 2 * K * 4)); CK(hipMalloc(&b.rowscale, (size_t)M * K * 4)); CK(hipMalloc(&b.stats_in, M * 8)); CK(hipMalloc(&b.stats_out, (size_t)M * (N / 32) * 8));
+    CK(hipMalloc(&b.film, 2 * K * 4)); CK(hipMalloc(&b.rowscale, (size_t)M * K * 4)); CK(hipMalloc(&b.stats_in, (size_t)M * (K / 32) * 8)); CK(hipMalloc(&b.stats_out, (size_t)M * (N / 32) * 8));
     hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, b.bias, (size_t)N, 0.1f);
     hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, b.rscale, (size_t)N, 0.2f);
     hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, b.resid, (size_t)M * N, 1.0f);
     hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, b.film, (size_t)2 * K, 1.0f);
     hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, b.rowscale, (size_t)M * K, 1.0f);
-    std::vector<float2> st(M, make_float2(0.5f, (float)K * 0.08f));
-    CK(hipMemcpy(b.stats_in, st.data(), M * 8, hipMemcpyHostToDevice));
+    const int NP = getenv("NP1") ? 1 : K / 32;          // LayerNorm partials per row, as the producers emit them
+    std::vector<float2> st((size_t)M * NP, make_float2(0.5f, (float)(K / NP) * 0.08f));
+    CK(hipMemcpy(b.stats_in, st.data(), st.size() * 8, hipMemcpyHostToDevice));
     unsigned* sink; CK(hipMalloc(&sink, 64));
     unsigned long long* stamps; CK(hipMalloc(&stamps, 8192 * 64));
     CK(hipStreamSynchronize(s));
@@ -97,7 +98,7 @@ int main(int argc, char** argv) {
     auto base = [&](int i) {
         GemmP p{};
         p.M = M; p.N = N; p.K = K; p.Kp = K; p.nt_total = N / 32; p.W = b.W[i % nrot];
-        p.a_scale = 1.f; p.hw = 1; p.ln_eps = 1e-6f; p.shuffle_r = 1; p.stats_np = 1; p.stats_cnt = K;
+        p.a_scale = 1.f; p.hw = 1; p.ln_eps = 1e-6f; p.shuffle_r = 1; p.stats_np = NP; p.stats_cnt = K / NP;
         p.bias = b.bias; p.rscale = b.rscale; p.resid = b.resid; p.ldr = N; p.out = b.out; p.ldo = N;
         return p;
     };
