@@ -513,22 +513,14 @@ struct EpBiasF32 {
 };
 // SCA: s = acc + bias (fp32 out, rows = faces) and, in place, G[pixels of the face][col] <- bf16(G * s): the
 // product x * sca(x) of conditional_naf.py:119 with the same rounding as the scale loader, so conv3 reads G plainly.
+// Runs as a tile epilogue in the skinny kernel (all threads sweep the faces' pixel rows, 16 B per access).
 struct EpScaBF16 {
-    static constexpr bool kStats = false, kTile = false;
+    static constexpr bool kStats = false, kTile = false, kScaTile = true;
     static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = 0.f; c.rscale = 1.f; return c; }
     static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
     static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float, const ColC& c) {
         v += c.bias;
         reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
-        unsigned short* __restrict__ g = p.scale_G + (size_t)row * p.scale_hw * p.ldo + col;
-        const int hw = p.scale_hw;
-        for (int r0 = 0; r0 < hw; r0 += 8) {               // loads batched 8 deep so they overlap
-            unsigned short t[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) t[r] = (r0 + r < hw) ? g[(size_t)(r0 + r) * p.ldo] : (unsigned short)0;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (r0 + r < hw) g[(size_t)(r0 + r) * p.ldo] = f32_to_bf16_bits(bf16_bits_to_f32(t[r]) * v);
-        }
         return v;
     }
 };
@@ -800,6 +792,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
     }
     HD_STAMP(5);
 }
+
+template <class EP, class = void> struct ep_is_sca_tile { static constexpr bool value = false; };
+template <class EP> struct ep_is_sca_tile<EP, decltype((void)EP::kScaTile)> { static constexpr bool value = EP::kScaTile; };
 
 // ----------------------------------------------------------------------------------- skinny kernel
 // HALF: 16-row workgroup tiles (WM = MT = 1 only): at M = 64 this doubles the workgroups (4 row groups instead
@@ -1101,6 +1096,47 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
                 if (p.pooled16) p.pooled16[(size_t)face * C2 + col] = f32_to_bf16_bits(pm);
             }
         }
+    } else if constexpr (ep_is_sca_tile<EP>::value) {
+        // ================= SCA: s tile -> LDS and S; then scale the faces' rows of G in place =================
+        {
+            const float bias = col < ncols ? p.bias[col] : 0.f;
+            for (int e = tid; e < C::BM * 32; e += C::THREADS) {
+                float v = bias;
+#pragma unroll
+                for (int w = 0; w < WK; ++w) v += red[w * TILE_F + e];
+                const int face = row0 + (e >> 5);
+                if (face < p.M && col < ncols) reinterpret_cast<float*>(p.out)[(size_t)face * p.ldo + col] = v;
+                red[e] = v;                                        // e is owned by this thread in every slice
+            }
+        }
+        __syncthreads();
+        const int hw = p.scale_hw;
+        if (hw > 0 && tile[0] * 32 + 32 <= ncols) {
+            const int units = C::BM * hw * 4;                      // (face, pixel, 8 columns)
+            for (int u0 = tid; u0 < units; u0 += C::THREADS * 2) {
+                uint4 g[2]; unsigned short* gp[2]; const float* sp[2]; bool ok[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int u = u0 + j * C::THREADS;
+                    const int f = u / (hw * 4), rem = u - f * hw * 4, r = rem >> 2, q = rem & 3;
+                    const int face = row0 + f;
+                    ok[j] = u < units && face < p.M;
+                    gp[j] = p.scale_G + ((size_t)(ok[j] ? face : 0) * hw + r) * p.ldo + tile[0] * 32 + q * 8;
+                    sp[j] = red + f * 32 + q * 8;
+                    g[j] = ok[j] ? *reinterpret_cast<const uint4*>(gp[j]) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (ok[j]) {
+                        float v[8];
+                        unpack8(g[j], v);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] *= sp[j][i];
+                        *reinterpret_cast<uint4*>(gp[j]) = pack8(v);
+                    }
+                }
+            }
+        }
     } else {
         // ================= element-wise epilogue, 32 lanes = one row of the tile =================
         const bool full = (row0 + C::BM <= p.M) && (tile[0] * 32 + 32 <= ncols);      // workgroup-uniform
@@ -1178,8 +1214,10 @@ inline hipError_t launch_skinny_auto(const GemmP& p, hipStream_t s) {
         const int tiles = (PAIR ? p.N / 2 : p.N) / 32;
         static const int half_m = getenv("HD_HALF_M") ? atoi(getenv("HD_HALF_M")) : 64;
         static const int half_wg = getenv("HD_HALF_WG") ? atoi(getenv("HD_HALF_WG")) : 256;
-        if (!no_half && p.M <= half_m && p.M % 16 == 0 && ((p.M + 31) / 32) * tiles < half_wg && chunks >= 16 && chunks % 8 == 0)
-            return launch_skinny<SkinnyCfg<1, 8, 1, PAIR, D, true>, LD, EP>(p, s);
+        if (!no_half && p.M <= half_m && p.M % 16 == 0 && ((p.M + 31) / 32) * tiles < half_wg) {
+            if (chunks >= 16 && chunks % 8 == 0) return launch_skinny<SkinnyCfg<1, 8, 1, PAIR, D, true>, LD, EP>(p, s);
+            if (chunks >= 8 && chunks % 4 == 0) return launch_skinny<SkinnyCfg<1, 4, 1, PAIR, D, true>, LD, EP>(p, s);
+        }
     }
     if constexpr (WM <= 1) if (chunks >= 16 && chunks % 8 == 0) return launch_skinny<SkinnyCfg<WM, 8, MT, PAIR, D>, LD, EP>(p, s);
     if constexpr (WM <= 2) if (chunks >= 8 && chunks % 4 == 0) return launch_skinny<SkinnyCfg<WM, 4, MT, PAIR, D>, LD, EP>(p, s);

@@ -383,7 +383,7 @@ hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStre
     if (lk == LK_BF16 && ek == EK_BIASBF16) return launch_tile<LdBF16Plain, EpBiasBF16, false>(p, mode, s);
     if (lk == LK_CONV_BF16 && ek == EK_BIASF32) return launch_tile<LdConv<true, false>, EpBiasF32, false>(p, mode, s);
     if (lk == LK_BF16 && ek == EK_PIXSHUF) return launch_tile<LdBF16Plain, EpPixShufF32, false>(p, mode, s);
-    if (lk == LK_BF16 && ek == EK_SCA) return launch_tile<LdBF16Plain, EpScaBF16, false>(p, mode, s);
+    if (lk == LK_BF16 && ek == EK_SCA) return launch_skinny_auto<1, 1, false, LdBF16Plain, EpScaBF16>(p, s);   // its in-place G scaling is a skinny tile epilogue
     if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, mode, s);
     return hipErrorInvalidValue;
 }
@@ -509,7 +509,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         *x_np = C / 32; *x_cnt = 32;
         return;
     }
-    const bool prescale = dwgate_ok(HW) && !no_fuse && HW <= 4;      // fused conv1 wrote pooled16; few pixels per face (more rows serialise the epilogue)
+    const bool prescale = dwgate_ok(HW) && !no_fuse && HW <= 16;      // fused conv1 wrote pooled16; few pixels per face (more rows serialise the epilogue)
     if (prescale) {
         {   // SCA on the bf16 pooled vector; its epilogue also scales G in place: G <- bf16(G * s)
             GemmP p = base_gemm(bw.sca, M / HW);
