@@ -502,6 +502,7 @@ struct ColC { float bias, bias2, rscale; };
 // out(fp32)[row][col] = act(acc + bias)
 struct EpBiasF32 {
     static constexpr bool kStats = true, kTile = false;
+    static __device__ __forceinline__ size_t stat_index(const GemmP& p, int row, int tile_idx) { return (size_t)row * (p.N >> 5) + tile_idx; }
     static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias ? p.bias[col] : 0.f; c.bias2 = 0.f; c.rscale = 1.f; return c; }
     static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
     static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float, const ColC& c) {
@@ -527,6 +528,7 @@ struct EpScaBF16 {
 // out(fp32) = resid + rscale[col] * (acc + bias)      (y = inp + x*beta, out = y + x*gamma)
 struct EpResidF32 {
     static constexpr bool kStats = true, kTile = false;
+    static __device__ __forceinline__ size_t stat_index(const GemmP& p, int row, int tile_idx) { return (size_t)row * (p.N >> 5) + tile_idx; }
     static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = 0.f; c.rscale = p.rscale[col]; return c; }
     static __device__ __forceinline__ float pre(const GemmP& p, int row, int col) {
         return reinterpret_cast<const float*>(p.resid)[(size_t)row * p.ldr + col];
@@ -552,26 +554,41 @@ struct EpGateBF16 {
         reinterpret_cast<unsigned short*>(p.out)[(size_t)row * p.ldo + col] = f32_to_bf16_bits((v1 + c.bias) * (v2 + c.bias2));
     }
 };
-// 1x1 conv (no bias) -> PixelShuffle(r) -> + skip : out[b, r*h+i, r*w+j, c] = acc[n = c*r*r + i*r + j]
+// 1x1 conv (no bias) -> PixelShuffle(r) -> + skip.  For r = 2 the weight columns are packed sub-pixel major
+// (n' = (2i + j) * Cout + c  <-  n = c*4 + 2i + j, PackOpts::S2 = 4), so a 32-column tile is a run of 32 output
+// channels of ONE output pixel: out[b, 2h+i, 2w+j, c..c+31] is a contiguous 128-byte store and the tile carries
+// a LayerNorm partial of that output row like every other producer of the residual stream.
 struct EpPixShufF32 {
-    static constexpr bool kStats = false, kTile = false;
+    static constexpr bool kStats = true, kTile = false;
     static __device__ __forceinline__ ColC col_init(const GemmP&, int) { ColC c; c.bias = 0.f; c.bias2 = 0.f; c.rscale = 1.f; return c; }
+    static __device__ __forceinline__ size_t out_row(const GemmP& p, int row, int sub) {       // Hin == Win == a power of two
+        const int lw = 31 - __builtin_clz(p.Win);
+        const int b = row >> (2 * lw), rem = row & ((1 << (2 * lw)) - 1);
+        const int h = rem >> lw, w = rem & (p.Win - 1);
+        return (((size_t)b << (lw + 1)) + (2 * h + (sub >> 1))) * (2 * p.Win) + (2 * w + (sub & 1));
+    }
     static __device__ __forceinline__ size_t index(const GemmP& p, int row, int col) {
-        if (p.shuffle_r == 2) {                                   // Hin == Win == a power of two
-            const int lw = 31 - __builtin_clz(p.Win);
-            const int b = row >> (2 * lw), rem = row & ((1 << (2 * lw)) - 1);
-            const int h = rem >> lw, w = rem & (p.Win - 1);
-            const int c = col >> 2, i = (col >> 1) & 1, j = col & 1;
-            return ((((size_t)b << (lw + 1)) + (2 * h + i)) * (2 * p.Win) + (2 * w + j)) * p.ldo + c;
+        if (p.shuffle_r == 2) {
+            const int lc = 31 - __builtin_clz(p.ldo);                                         // Cout is a power of two
+            return out_row(p, row, col >> lc) * p.ldo + (col & (p.ldo - 1));
         }
         return (size_t)row * p.ldo + col;
+    }
+    static __device__ __forceinline__ size_t stat_index(const GemmP& p, int row, int tile_idx) {
+        if (p.shuffle_r == 2) {
+            const int lt = 31 - __builtin_clz(p.ldo >> 5);                                    // tiles per output row
+            return out_row(p, row, tile_idx >> lt) * (p.ldo >> 5) + (tile_idx & ((p.ldo >> 5) - 1));
+        }
+        return (size_t)row * (p.N >> 5) + tile_idx;
     }
     static __device__ __forceinline__ float pre(const GemmP& p, int row, int col) {
         return p.resid ? reinterpret_cast<const float*>(p.resid)[index(p, row, col)] : 0.f;
     }
     static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float r, const ColC&) {
         v += r;
-        reinterpret_cast<float*>(p.out)[index(p, row, col)] = v;
+        const size_t o = index(p, row, col);
+        reinterpret_cast<float*>(p.out)[o] = v;
+        if (p.out16) p.out16[o] = f32_to_bf16_bits(v);
         return v;
     }
 };
@@ -639,7 +656,7 @@ __device__ __forceinline__ void tile_epilogue_mfma(const GemmP& p, const f32x16_
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = rbase + (i & 3) + 8 * (i >> 2);
-                    if (FULL || row < p.M) p.stats_out[(size_t)row * (p.N >> 5) + tile_idx] = ms[i];
+                    if (FULL || row < p.M) p.stats_out[EP::stat_index(p, row, tile_idx)] = ms[i];
                 }
             }
         }
@@ -891,7 +908,7 @@ __device__ __forceinline__ void skinny_rows_epilogue(const GemmP& p, const float
                 for (int it = 0; it < NIT; ++it) {
                     const int e = it * C::THREADS + tid;
                     const int row = row0 + (e >> 5);
-                    if ((EVEN || e < C::BM * 32) && (FULL || row < p.M)) p.stats_out[(size_t)row * (p.N >> 5) + tile_idx] = ms[it];
+                    if ((EVEN || e < C::BM * 32) && (FULL || row < p.M)) p.stats_out[EP::stat_index(p, row, tile_idx)] = ms[it];
                 }
             }
         }

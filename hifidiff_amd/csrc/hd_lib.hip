@@ -584,10 +584,11 @@ void add_down(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const P
 
 // 1x1 conv (no bias) + PixelShuffle(r) + skip add, written in place over the skip buffer
 void add_up(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const void* in, bool in_bf16, int M_in,
-            int H_in, int C_in, float* out, const float* skip, int r) {
+            int H_in, int C_in, float* out, const float* skip, int r, unsigned short* out16 = nullptr, float2* stats = nullptr) {
     GemmP p = base_gemm(w, M_in);
     p.A = in; p.lda = C_in; p.Hin = H_in; p.Win = H_in; p.shuffle_r = r;
     p.out = out; p.ldo = w.N / (r * r); p.resid = skip; p.bias = nullptr;
+    p.out16 = out16; p.stats_out = stats;
     add_gemm(c, prog, name, p, in_bf16 ? LK_BF16 : LK_F32, EK_PIXSHUF);
 }
 
@@ -729,9 +730,10 @@ int build_denoiser_program(hd_ctx* c) {
     for (int i = 0; i < 4; ++i) {
         const int l = 3 - i;
         const Level &hi = c->ch->lv[l + 1], &lo = c->ch->lv[l];
-        add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], hi.Yb, true, hi.M, hi.H, hi.C, lo.X, lo.X, 2);
-        add_row_stats(prog, "ups." + std::to_string(i) + ".row_stats", lo.X, lo.Xb, lo.sx, lo.M, lo.C);
-        np = 1; cnt = lo.C;
+        // x = PixelShuffle(up(x)) + enc_skip (model.py:249-251); the epilogue also leaves the bf16 copy and the
+        // LayerNorm partials of the new rows (one per 32 channels)
+        add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], hi.Yb, true, hi.M, hi.H, hi.C, lo.X, lo.X, 2, lo.Xb, lo.sx);
+        np = lo.C / 32; cnt = 32;
         for (int j = 0; j < 2; ++j) {
             GateOut g; g.gate_c = c->ch->gate_c[i + 1]; g.gate_s = c->ch->gate_s[i + 1];
             add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt, j == 1 ? &g : nullptr);
@@ -1069,10 +1071,10 @@ int hd_finalize_weights(hd_ctx* c) {
     // ---- downs / ups / fpg convs / idc_conv ----
     for (int i = 0; i < 4; ++i) {
         rc |= pack_weight(c, "denoiser.downs." + std::to_string(i), &c->den_down[i]);
-        rc |= pack_weight(c, "denoiser.ups." + std::to_string(i) + ".0", &c->den_up[i]);
+        { PackOpts o; o.S2 = 4; rc |= pack_weight(c, "denoiser.ups." + std::to_string(i) + ".0", &c->den_up[i], o); }   // sub-pixel major (EpPixShufF32)
         rc |= pack_weight(c, "fpg.downs." + std::to_string(i), &c->fpg_down[i]);
     }
-    for (int i = 0; i < 5; ++i) rc |= pack_weight(c, "fpg.convs." + std::to_string(i) + ".0", &c->fpg_convs[i]);
+    for (int i = 0; i < 5; ++i) { PackOpts o; o.S2 = i ? 4 : 1; rc |= pack_weight(c, "fpg.convs." + std::to_string(i) + ".0", &c->fpg_convs[i], o); }
     { PackOpts o; o.S2 = c->S * c->S; rc |= pack_weight(c, "denoiser.idc_conv", &c->idc_conv, o); }
     if (rc) return rc;
     // ---- HCAs ----
