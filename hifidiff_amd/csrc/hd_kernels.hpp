@@ -56,52 +56,60 @@ __global__ void pack_weight_kernel(const PackP p) {
 }
 
 // ----------------------------------------------------------------------------------- intro / ending
-// intro: Conv2d(4,128,3,pad 1) on the NCHW latent -> channels-last fp32 (models/denoiser/model.py:159-167,235).
-// fp32 FMA (K = 36 is too small for MFMA).  The first thread also advances the loop's step counter.
-__global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict__ lat, const float* __restrict__ w,
+// intro: Conv2d(4,128,3,pad 1) on the NCHW latent -> channels-last fp32 + bf16 copy + LayerNorm partial
+// (models/denoiser/model.py:159-167,235).  fp32 FMA (K = 36 is too small for MFMA).  One wave per run of 16
+// pixels of an image row, lanes over output channels (co = lane, lane + 64): the lane's 72 weights stay in
+// registers (wT is the weight re-laid as [ci*9 + tap][co]: coalesced loads), the 3 x 18 x 4 latent patch of
+// the run sits in LDS and is read as broadcasts.  The first thread also advances the loop's step counter.
+__global__ void intro_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT) {    // w[co][36] -> wT[36][co]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 128 * 36) return;
+    const int co = i / 36;
+    wT[(i - co * 36) * 128 + co] = w[i];
+}
+__global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict__ lat, const float* __restrict__ wT,
                                                           const float* __restrict__ b, float* __restrict__ out,
                                                           unsigned short* __restrict__ out16, float2* __restrict__ stats, int B, int L,
                                                           StepState* st, int advance) {
-    __shared__ float wt[36][128];
-    __shared__ float patch[16][36];
-    __shared__ float tile[16][128];
+    __shared__ float patch[4][4][3][20];                                 // [wave][ci][row][x0-1 .. x0+16] (+pad)
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;
-    for (int i = threadIdx.x; i < 36 * 128; i += 256) {
-        const int co = i / 36, r = i - co * 36;           // w[co][ci][ky][kx], r = ci*9 + tap
-        wt[r][co] = w[i];
-    }
-    const int M = B * L * L;
-    const int p0 = blockIdx.x * 16;
-    for (int i = threadIdx.x; i < 16 * 36; i += 256) {
-        const int pl = i / 36, r = i - pl * 36;
-        const int ci = r / 9, tap = r - ci * 9;
-        const int pix = p0 + pl;
-        float v = 0.f;
-        if (pix < M) {
-            const int bb = pix / (L * L), rem = pix - bb * L * L;
-            const int y = rem / L + tap / 3 - 1, x = rem % L + tap % 3 - 1;
-            if (y >= 0 && y < L && x >= 0 && x < L) v = lat[((size_t)(bb * 4 + ci) * L + y) * L + x];
-        }
-        patch[pl][r] = v;
-    }
-    __syncthreads();
-    const int co = threadIdx.x & 127;
-    for (int pl = threadIdx.x >> 7; pl < 16; pl += 2) {
-        const int pix = p0 + pl;
-        float acc = b[co];
-#pragma unroll
-        for (int r = 0; r < 36; ++r) acc += patch[pl][r] * wt[r][co];
-        tile[pl][co] = acc;
-        if (pix < M) { out[(size_t)pix * 128 + co] = acc; out16[(size_t)pix * 128 + co] = f32_to_bf16_bits(acc); }
-    }
-    __syncthreads();
-    // LayerNorm statistics of the 128-channel rows for the first block's norm1: (mean, M2), one partial
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int pl = wave; pl < 16; pl += 4) {
-        const float v0 = tile[pl][lane], v1 = tile[pl][lane + 64];
-        const float mean = wave_sum(v0 + v1) * (1.0f / 128.0f);
-        const float m2 = wave_sum((v0 - mean) * (v0 - mean) + (v1 - mean) * (v1 - mean));
-        if (lane == 0 && p0 + pl < M) stats[p0 + pl] = make_float2(mean, m2);
+    const int nseg = B * L * (L >> 4);
+    const int seg = blockIdx.x * 4 + wave;
+    if (seg >= nseg) return;                                             // whole wave; no block-wide barrier below
+    const int spr = L >> 4;
+    const int bb = seg / (L * spr), rem = seg - bb * L * spr, y = rem / spr, x0 = (rem - y * spr) << 4;
+    for (int i = lane; i < 4 * 3 * 18; i += 64) {
+        const int ci = i / 54, r = (i - ci * 54) / 18, xx = i - ci * 54 - r * 18;
+        const int yy = y + r - 1, x = x0 + xx - 1;
+        patch[wave][ci][r][xx] = (yy >= 0 && yy < L && x >= 0 && x < L) ? lat[((size_t)(bb * 4 + ci) * L + yy) * L + x] : 0.f;
+    }
+    float wl[36][2];
+#pragma unroll
+    for (int r = 0; r < 36; ++r) { wl[r][0] = wT[r * 128 + lane]; wl[r][1] = wT[r * 128 + lane + 64]; }
+    const float b0 = b[lane], b1 = b[lane + 64];
+    __builtin_amdgcn_wave_barrier();
+    const size_t row0 = ((size_t)bb * L + y) * L + x0;
+#pragma unroll 4
+    for (int px = 0; px < 16; ++px) {
+        float a0 = b0, a1 = b1;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float v = patch[wave][ci][r][px + k];
+                    a0 += v * wl[ci * 9 + r * 3 + k][0];
+                    a1 += v * wl[ci * 9 + r * 3 + k][1];
+                }
+        const size_t o = (row0 + px) * 128;
+        out[o + lane] = a0; out[o + lane + 64] = a1;
+        out16[o + lane] = f32_to_bf16_bits(a0); out16[o + lane + 64] = f32_to_bf16_bits(a1);
+        // LayerNorm statistics of the 128-channel row for the first block's norm1: (mean, M2), one partial
+        const float s1 = wave_sum(a0 + a1), s2 = wave_sum(a0 * a0 + a1 * a1);
+        const float mean = s1 * (1.0f / 128.0f);
+        if (lane == 0) stats[row0 + px] = make_float2(mean, fmaxf(s2 - s1 * mean, 0.f));
     }
 }
 
@@ -129,38 +137,115 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     if (lane == 0) stats[row] = make_float2(mean, q);
 }
 
-// ending: Conv2d(128,4,3,pad 1) channels-last fp32 -> NCHW eps (models/denoiser/model.py:168-176,261).
-// One wave per pixel, lanes over input channels, wave reduction.
-__global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restrict__ X, const float* __restrict__ w,
+// ending: Conv2d(128,4,3,pad 1) channels-last fp32 -> NCHW eps (models/denoiser/model.py:168-176,261), and --
+// in the sampling loop -- the scheduler update of the same elements (sched_update below) plus the staging of
+// the next step's FiLM row, so the step ends with this launch.
+// One wave per run of 16 pixels of an image row; lanes over input channels (ci = lane, lane + 64).  The lane's
+// 72 weights stay in registers for the whole run (wT is the weight re-laid as [tap][co][ci], so these are
+// coalesced loads) and the 3x3 window slides along x (one new column = 6 loads per pixel).  The 64 per-lane
+// partial sums (16 pixels x 4 outputs) are reduced over the wave with DPP.
+struct SchedArgs {
+    float* lat;                   // chain-local latents x_t -> x_{t-1} (NULL: plain eps evaluation)
+    const float* coef;            // [n_steps][7]
+    const StepState* st;
+    int elem0, n_total;           // position of this chain's elements inside the whole batch (noise indexing)
+    const float* film_table; float* film_cur; int film_total;
+};
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned step, unsigned idx);
+// x0 = clamp((x - c0*eps)/c1, +-c2);  x <- c3*x0 + c4*x + c5*eps + c6*z      (hd_schedule in the C-ABI)
+__device__ __forceinline__ float sched_update(float xv, float e, const float* c, const StepState* st, int step, size_t gi, int n_total) {
+    float x0 = (xv - c[0] * e) / c[1];
+    x0 = fminf(fmaxf(x0, -c[2]), c[2]);
+    float r = c[3] * x0 + c[4] * xv + c[5] * e;
+    if (c[6] != 0.f) {
+        const float z = st->noise ? st->noise[(size_t)step * n_total + gi] : philox_normal(st->seed, (unsigned)step, (unsigned)gi);
+        r += c[6] * z;
+    }
+    return r;
+}
+__global__ void ending_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT) {   // w[co][ci][tap] -> wT[tap][co][ci]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 128 * 9) return;
+    const int co = i / (128 * 9), r = i - co * 128 * 9, ci = r / 9, tap = r - ci * 9;
+    wT[(tap * 4 + co) * 128 + ci] = w[i];
+}
+__global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restrict__ X, const float* __restrict__ wT,
                                                            const float* __restrict__ b, float* __restrict__ eps,
-                                                           int B, int L) {
-    __shared__ float wt[9][4][128];                       // [tap][co][ci]
-    for (int i = threadIdx.x; i < 4 * 128 * 9; i += 256) {
-        const int co = i / (128 * 9), r = i - co * 128 * 9, ci = r / 9, tap = r - ci * 9;
-        wt[tap][co][ci] = w[i];
-    }
-    __syncthreads();
+                                                           int B, int L, const SchedArgs sa) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int M = B * L * L;
-    const int pix = blockIdx.x * 4 + wave;
-    if (pix >= M) return;
-    const int bb = pix / (L * L), rem = pix - bb * L * L, y = rem / L, x = rem - y * L;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        if (yy < 0 || yy >= L || xx < 0 || xx >= L) continue;
-        const float* xp = X + ((size_t)(bb * L + yy) * L + xx) * 128;
-        const float v0 = xp[lane], v1 = xp[lane + 64];
-        a0 += v0 * wt[tap][0][lane] + v1 * wt[tap][0][lane + 64];
-        a1 += v0 * wt[tap][1][lane] + v1 * wt[tap][1][lane + 64];
-        a2 += v0 * wt[tap][2][lane] + v1 * wt[tap][2][lane + 64];
-        a3 += v0 * wt[tap][3][lane] + v1 * wt[tap][3][lane + 64];
+    const int nseg = B * L * (L >> 4);                                   // runs of 16 pixels (L is a multiple of 16)
+    const int nb_conv = (nseg + 3) >> 2;
+    if ((int)blockIdx.x >= nb_conv) {
+        // trailing workgroups: stage the NEXT step's FiLM row at a fixed address, so that no LayerNorm loader of
+        // the next replay has to chase the step index through memory before it can fetch its gain/bias
+        const int step = sa.st->step;
+        if (step + 1 >= sa.st->n_steps) return;
+        const float4* src = reinterpret_cast<const float4*>(sa.film_table + (size_t)(step + 1) * sa.film_total);
+        const int i = ((int)blockIdx.x - nb_conv) * 256 + (int)threadIdx.x;
+        if (i < sa.film_total / 4) reinterpret_cast<float4*>(sa.film_cur)[i] = src[i];
+        return;
     }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-    if (lane == 0) {
-        const size_t o = ((size_t)bb * 4 * L + y) * L + x, cs = (size_t)L * L;
-        eps[o] = a0 + b[0]; eps[o + cs] = a1 + b[1]; eps[o + 2 * cs] = a2 + b[2]; eps[o + 3 * cs] = a3 + b[3];
+    const int seg = blockIdx.x * 4 + wave;
+    if (seg >= nseg) return;                                             // whole wave; no block-wide barrier below
+    const int spr = L >> 4;                                              // runs per image row
+    const int bb = seg / (L * spr), rem = seg - bb * L * spr, y = rem / spr, x0 = (rem - y * spr) << 4;
+    float wl[9][4][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            wl[tap][co][0] = wT[(tap * 4 + co) * 128 + lane];
+            wl[tap][co][1] = wT[(tap * 4 + co) * 128 + lane + 64];
+        }
+    // column loader: the three rows y-1, y, y+1 at image column x (zeros outside the image)
+    const float* face = X + (size_t)bb * L * L * 128;
+    auto load_col = [&](int x, float (&c)[3][2]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            const bool in = yy >= 0 && yy < L && x >= 0 && x < L;      // wave-uniform
+            const float* q = face + ((size_t)(in ? yy : y) * L + (in ? x : x0)) * 128;
+            const float v0 = q[lane], v1 = q[lane + 64];
+            c[r][0] = in ? v0 : 0.f; c[r][1] = in ? v1 : 0.f;
+        }
+    };
+    float cl[3][2], cc[3][2], cr[3][2];
+    load_col(x0 - 1, cl);
+    load_col(x0, cc);
+    float part[16][4];
+#pragma unroll
+    for (int px = 0; px < 16; ++px) {
+        load_col(x0 + px + 1, cr);
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                a += cl[r][0] * wl[r * 3 + 0][co][0] + cl[r][1] * wl[r * 3 + 0][co][1];
+                a += cc[r][0] * wl[r * 3 + 1][co][0] + cc[r][1] * wl[r * 3 + 1][co][1];
+                a += cr[r][0] * wl[r * 3 + 2][co][0] + cr[r][1] * wl[r * 3 + 2][co][1];
+            }
+            part[px][co] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cl[r][0] = cc[r][0]; cl[r][1] = cc[r][1]; cc[r][0] = cr[r][0]; cc[r][1] = cr[r][1]; }
+    }
+    // wave reduction of the 64 partial sums; lane j keeps value j = (pixel j >> 2, output j & 3)
+    float mine = 0.f;
+#pragma unroll
+    for (int px = 0; px < 16; ++px)
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            const float t = wave_sum(part[px][co]);
+            if (lane == px * 4 + co) mine = t;
+        }
+    const int co = lane & 3, x = x0 + (lane >> 2);
+    const size_t o = (((size_t)bb * 4 + co) * L + y) * L + x;           // NCHW
+    const float e = mine + b[co];
+    eps[o] = e;
+    if (sa.lat) {
+        const int step = sa.st->step;
+        sa.lat[o] = sched_update(sa.lat[o], e, sa.coef + (size_t)step * 7, sa.st, step, (size_t)sa.elem0 + o, sa.n_total);
     }
 }
 
@@ -310,38 +395,8 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
-// x0 = clamp((x - c0*eps)/c1, +-c2);  x <- c3*x0 + c4*x + c5*eps + c6*z      (hd_schedule in the C-ABI)
-// x/eps point at this chain's faces; elem0 / n_total place them inside the whole batch so that the noise
-// tensor and the Philox counters are indexed exactly as for an unsplit batch.
-__global__ void sched_step_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ coef,
-                                  const StepState* __restrict__ st, int n, int elem0, int n_total,
-                                  const float* __restrict__ film_table, float* __restrict__ film_cur, int film_total) {
-    const int step = st->step;
-    const int nb = (n + (int)blockDim.x - 1) / (int)blockDim.x;
-    if ((int)blockIdx.x >= nb) {
-        // trailing workgroups: stage the NEXT step's FiLM row at a fixed address, so that no LayerNorm loader of
-        // the next replay has to chase the step index through memory before it can fetch its gain/bias
-        if (step + 1 >= st->n_steps) return;
-        const float4* src = reinterpret_cast<const float4*>(film_table + (size_t)(step + 1) * film_total);
-        float4* dst = reinterpret_cast<float4*>(film_cur);
-        const int i = ((int)blockIdx.x - nb) * (int)blockDim.x + (int)threadIdx.x;
-        if (i < film_total / 4) dst[i] = src[i];
-        return;
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* c = coef + (size_t)step * 7;
-    const float xv = x[i], e = eps[i];
-    float x0 = (xv - c[0] * e) / c[1];
-    x0 = fminf(fmaxf(x0, -c[2]), c[2]);
-    float r = c[3] * x0 + c[4] * xv + c[5] * e;
-    if (c[6] != 0.f) {
-        const float z = st->noise ? st->noise[(size_t)step * n_total + elem0 + i] : philox_normal(st->seed, (unsigned)step, (unsigned)(elem0 + i));
-        r += c[6] * z;
-    }
-    x[i] = r;
-}
-
+// The sampling loop applies the scheduler update inside ending_conv_kernel (sched_update); this kernel serves
+// hd_scheduler_step.
 struct Coef7 { float c[7]; };
 __global__ void sched_step_direct_kernel(float* __restrict__ x, const float* __restrict__ eps, const Coef7 k,
                                          const float* __restrict__ noise, unsigned long long seed, int step, long long n) {

@@ -103,6 +103,7 @@ struct hd_ctx {
     std::vector<BlockW> den_blocks, fpg_blocks;       // execution order
     std::map<std::string, int> den_block_index;
     PackedW den_down[4], den_up[4], fpg_down[4], fpg_convs[5], idc_conv;
+    float *intro_wT = nullptr, *fpg_intro_wT = nullptr, *ending_wT = nullptr;   // intro/ending weights re-laid for coalesced per-lane loads
     HcaW hca[5];
     ResConv res_conv1;
     std::vector<ResBlock> res_blocks;
@@ -704,11 +705,11 @@ int build_denoiser_program(hd_ctx* c) {
     const RawTensor *iw = find_raw(c, "denoiser.intro.weight"), *ib = find_raw(c, "denoiser.intro.bias");
     const RawTensor *ew = find_raw(c, "denoiser.ending.weight"), *eb = find_raw(c, "denoiser.ending.bias");
     {
-        const float *lat = c->ch->lat, *w = iw->dev, *b = ib->dev; float* out = c->ch->lv[0].X; float2* sx = c->ch->lv[0].sx;
+        const float *lat = c->ch->lat, *w = c->intro_wT, *b = ib->dev; float* out = c->ch->lv[0].X; float2* sx = c->ch->lv[0].sx;
         unsigned short* xb = c->ch->lv[0].Xb;
         const int M = c->ch->lv[0].M;
         prog.push_back({"intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M / 16 + 3) / 4), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
@@ -741,10 +742,22 @@ int build_denoiser_program(hd_ctx* c) {
         add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
     }
     {
-        const float *X = c->ch->lv[0].Y, *w = ew->dev, *b = eb->dev; float* eps = c->ch->eps;
+        const float *X = c->ch->lv[0].Y, *w = c->ending_wT, *b = eb->dev; float* eps = c->ch->eps;
         const int M = c->ch->lv[0].M;
+        Chain* chp = c->ch;
         prog.push_back({"ending", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(ending_conv_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, w, b, eps, B, L);
+                            // sampling loop (film_from_cur): the launch also applies the scheduler update to this
+                            // chain's latents and stages the next step's FiLM row
+                            SchedArgs sa{};
+                            unsigned nb = (unsigned)((M / 16 + 3) / 4);
+                            if (c->film_from_cur) {
+                                const size_t per_face = (size_t)4 * L * L;
+                                sa.lat = chp->lat; sa.coef = c->coef_dev; sa.st = chp->step_state;
+                                sa.elem0 = (int)(chp->face0 * per_face); sa.n_total = (int)(c->B * per_face);
+                                sa.film_table = c->film_table; sa.film_cur = chp->film_cur; sa.film_total = c->film_total;
+                                nb += (unsigned)((c->film_total / 4 + 255) / 256);
+                            }
+                            hipLaunchKernelGGL(ending_conv_kernel, dim3(nb), dim3(256), 0, s, X, w, b, eps, B, L, sa);
                             return hipGetLastError();
                         }});
         prog.back().out = eps; prog.back().out_elems = (size_t)B * 4 * L * L;
@@ -788,11 +801,11 @@ void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
     const int B = c->ch->B, L = c->L;
     const RawTensor *iw = find_raw(c, "fpg.intro.weight"), *ib = find_raw(c, "fpg.intro.bias");
     {
-        const float *w = iw->dev, *b = ib->dev; float* out = c->ch->lv[0].X; const int M = c->ch->lv[0].M; float2* sx = c->ch->lv[0].sx;
+        const float *w = c->fpg_intro_wT, *b = ib->dev; float* out = c->ch->lv[0].X; const int M = c->ch->lv[0].M; float2* sx = c->ch->lv[0].sx;
         unsigned short* xb = c->ch->lv[0].Xb;
         Chain* chp = c->ch;
         prog.push_back({"fpg.intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M + 15) / 16), dim3(256), 0, s, cr_latent_dev, w, b, out, xb, sx, B, L, chp->step_state, 0);
+                            hipLaunchKernelGGL(intro_conv_kernel, dim3((M / 16 + 3) / 4), dim3(256), 0, s, cr_latent_dev, w, b, out, xb, sx, B, L, chp->step_state, 0);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
@@ -1068,6 +1081,17 @@ int hd_finalize_weights(hd_ctx* c) {
     }
     for (const BlockW& bw : c->fpg_blocks) { rc = copy_ln(bw, c->fpg_ln_pack); if (rc) return rc; }
     HIPCHECK(c, hipMemcpy(c->film_blocks_dev, fbs.data(), fbs.size() * sizeof(FilmBlock), hipMemcpyHostToDevice));
+    // ---- intro / ending weights re-laid for coalesced per-lane loads ----
+    {
+        const RawTensor *iw = find_raw(c, "denoiser.intro.weight"), *fw = find_raw(c, "fpg.intro.weight"), *ew = find_raw(c, "denoiser.ending.weight");
+        if (!iw || !fw || !ew) HD_FAIL(c, HD_ERR_INVALID, "intro/ending weights missing");
+        rc |= dev_alloc(c, &c->intro_wT, 36 * 128); rc |= dev_alloc(c, &c->fpg_intro_wT, 36 * 128); rc |= dev_alloc(c, &c->ending_wT, 9 * 4 * 128);
+        if (rc) return rc;
+        hipLaunchKernelGGL(intro_weight_layout_kernel, dim3(18), dim3(256), 0, 0, iw->dev, c->intro_wT);
+        hipLaunchKernelGGL(intro_weight_layout_kernel, dim3(18), dim3(256), 0, 0, fw->dev, c->fpg_intro_wT);
+        hipLaunchKernelGGL(ending_weight_layout_kernel, dim3(18), dim3(256), 0, 0, ew->dev, c->ending_wT);
+        HIPCHECK(c, hipGetLastError());
+    }
     // ---- downs / ups / fpg convs / idc_conv ----
     for (int i = 0; i < 4; ++i) {
         rc |= pack_weight(c, "denoiser.downs." + std::to_string(i), &c->den_down[i]);
@@ -1343,13 +1367,6 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
             hipError_t e = hipStreamBeginCapture(ch.stream, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 for (size_t k = 0; k < ch.program.size() && e == hipSuccess; ++k) e = ch.program[k].run(ch.stream);
-                if (e == hipSuccess) {
-                    const int nel = (int)(ch.B * per_face);
-                    const unsigned nb_sched = (unsigned)((nel + 255) / 256), nb_film = (unsigned)((c->film_total / 4 + 255) / 256);
-                    hipLaunchKernelGGL(sched_step_kernel, dim3(nb_sched + nb_film), dim3(256), 0, ch.stream, ch.lat, ch.eps, c->coef_dev,
-                                       ch.step_state, nel, (int)(ch.face0 * per_face), (int)nlat, c->film_table, ch.film_cur, c->film_total);
-                    e = hipGetLastError();
-                }
                 hipError_t e2 = hipStreamEndCapture(ch.stream, &graph);
                 if (e == hipSuccess) e = e2;
             }
