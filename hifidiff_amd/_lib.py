@@ -20,7 +20,7 @@ SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_gemm.hpp",
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
 
 EXPORTS = [
-    "hd_create", "hd_destroy", "hd_last_error", "hd_load_weights", "hd_finalize_weights", "hd_prepare",
+    "hd_create", "hd_create_unconditional", "hd_prepare_unconditional", "hd_destroy", "hd_last_error", "hd_load_weights", "hd_finalize_weights", "hd_prepare",
     "hd_prepare_from_priors", "hd_fpg", "hd_idc", "hd_eps", "hd_sample", "hd_scheduler_step", "hd_num_ops", "hd_num_chains",
     "hd_debug_limit_ops", "hd_debug_op_name", "hd_debug_read_op", "hd_debug_read", "hd_set_profiling", "hd_get_profile",
 ]
@@ -63,6 +63,8 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
     L.hd_create.argtypes = [ctypes.POINTER(vp), i32, i32]
+    L.hd_create_unconditional.argtypes = [ctypes.POINTER(vp), i32, i32]
+    L.hd_prepare_unconditional.argtypes = [vp, i32, vp]
     L.hd_destroy.argtypes = [vp]; L.hd_destroy.restype = None
     L.hd_last_error.argtypes = [vp]; L.hd_last_error.restype = ctypes.c_char_p
     L.hd_load_weights.argtypes = [vp, ctypes.POINTER(TensorDesc), i32]

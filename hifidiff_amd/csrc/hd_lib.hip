@@ -94,6 +94,7 @@ static std::string g_create_error;
 
 struct hd_ctx {
     int L = 16, device = 0, S = 1;            // S = L/16
+    bool conditional = true;                  // false: the unconditional Denoiser (models/denoiser/model.py:32-134): no priors, HCAs or IDC
     std::string err;
     std::unordered_map<std::string, RawTensor> raw;
     std::vector<void*> allocs;
@@ -207,13 +208,13 @@ void m_naf(std::vector<std::pair<std::string, Shape>>& m, const std::string& p, 
     m_conv(m, p + ".conv5", c, c, 1, 1);
     for (const char* n : {".norm1", ".norm2"}) { m.push_back({p + n + ".weight", {c}}); m.push_back({p + n + ".bias", {c}}); }
 }
-std::vector<std::pair<std::string, Shape>> build_manifest(int L) {
+std::vector<std::pair<std::string, Shape>> build_manifest(int L, bool conditional = true) {
     std::vector<std::pair<std::string, Shape>> m;
     const int enc[4] = {2, 2, 4, 8}, res_layers[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
     // idc
-    m_conv(m, "idc.conv1", 64, 3, 7, 7, false); m_bn(m, "idc.batch_norm1", 64);
+    if (conditional) { m_conv(m, "idc.conv1", 64, 3, 7, 7, false); m_bn(m, "idc.batch_norm1", 64); }
     int cin = 64;
-    for (int li = 0; li < 4; ++li)
+    for (int li = 0; li < 4 && conditional; ++li)
         for (int b = 0; b < res_layers[li]; ++b) {
             std::string q = "idc.layer" + std::to_string(li + 1) + "." + std::to_string(b);
             m_conv(m, q + ".conv1", planes[li], cin, 1, 1); m_bn(m, q + ".batch_norm1", planes[li]);
@@ -235,6 +236,7 @@ std::vector<std::pair<std::string, Shape>> build_manifest(int L) {
     for (int i = 0; i < 4; ++i) { m_conv(m, d + ".ups." + std::to_string(i) + ".0", c * 2, c, 1, 1, false); c /= 2; }
     c = WIDTH;
     for (int i = 0; i < 4; ++i) { m_conv(m, d + ".downs." + std::to_string(i), 2 * c, c, 2, 2); c *= 2; }
+    if (!conditional) return m;                       // Denoiser: time_mlp, intro/ending, blocks, ups, downs only
     c = WIDTH * 16;
     for (int i = 0; i < 5; ++i) {
         std::string p = d + ".hcas." + std::to_string(i);
@@ -722,27 +724,29 @@ int build_denoiser_program(hd_ctx* c) {
         add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
         np = c->ch->lv[l + 1].C / 32; cnt = 32;
     }
-    // x + idc_conv(id) -> HCA0 (model.py:245-247): the add and the gate are applied by the last mid block's conv5 epilogue
+    // x + idc_conv(id) -> HCA0 (model.py:245-247): the add and the gate are applied by the last mid block's conv5 epilogue.
+    // The unconditional Denoiser (model.py:117-128) has neither: the up-convs read the blocks' own bf16 output.
+    const bool cond = c->conditional;
     for (int j = 0; j < 8; ++j) {
         GateOut g0; g0.gate_c = c->ch->gate_c[0]; g0.gate_s = c->ch->gate_s[0]; g0.add = c->ch->idc_term;
-        add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[4], nullptr, &np, &cnt, j == 7 ? &g0 : nullptr);
+        add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[4], nullptr, &np, &cnt, (cond && j == 7) ? &g0 : nullptr);
     }
-    add_hca(c, prog, "hcas.0", c->hca[0], c->ch->lv[4].Xg, c->ch->lv[4].Y, c->ch->lv[4].Yb, c->ch->lv[4].M, c->ch->lv[4].H);
+    if (cond) add_hca(c, prog, "hcas.0", c->hca[0], c->ch->lv[4].Xg, c->ch->lv[4].Y, c->ch->lv[4].Yb, c->ch->lv[4].M, c->ch->lv[4].H);
     for (int i = 0; i < 4; ++i) {
         const int l = 3 - i;
         const Level &hi = c->ch->lv[l + 1], &lo = c->ch->lv[l];
         // x = PixelShuffle(up(x)) + enc_skip (model.py:249-251); the epilogue also leaves the bf16 copy and the
         // LayerNorm partials of the new rows (one per 32 channels)
-        add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], hi.Yb, true, hi.M, hi.H, hi.C, lo.X, lo.X, 2, lo.Xb, lo.sx);
+        add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], cond ? hi.Yb : hi.Xb, true, hi.M, hi.H, hi.C, lo.X, lo.X, 2, lo.Xb, lo.sx);
         np = lo.C / 32; cnt = 32;
         for (int j = 0; j < 2; ++j) {
             GateOut g; g.gate_c = c->ch->gate_c[i + 1]; g.gate_s = c->ch->gate_s[i + 1];
-            add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt, j == 1 ? &g : nullptr);
+            add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt, (cond && j == 1) ? &g : nullptr);
         }
-        add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
+        if (cond) add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
     }
     {
-        const float *X = c->ch->lv[0].Y, *w = c->ending_wT, *b = eb->dev; float* eps = c->ch->eps;
+        const float *X = cond ? c->ch->lv[0].Y : c->ch->lv[0].X, *w = c->ending_wT, *b = eb->dev; float* eps = c->ch->eps;
         const int M = c->ch->lv[0].M;
         Chain* chp = c->ch;
         prog.push_back({"ending", [=](hipStream_t s) -> hipError_t {
@@ -930,6 +934,12 @@ extern "C" {
 
 const char* hd_last_error(const hd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+int hd_create_unconditional(hd_ctx** out, int latent_res, int device) {
+    int rc = hd_create(out, latent_res, device);
+    if (rc == HD_OK) (*out)->conditional = false;
+    return rc;
+}
+
 int hd_create(hd_ctx** out, int latent_res, int device) {
     if (!out) return HD_ERR_INVALID;
     *out = nullptr;
@@ -1007,7 +1017,7 @@ int hd_finalize_weights(hd_ctx* c) {
     if (c->finalized) return HD_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     // ---- strict key / shape check ----
-    const auto man = build_manifest(c->L);
+    const auto man = build_manifest(c->L, c->conditional);
     for (const auto& e : man) {
         const RawTensor* r = find_raw(c, e.first);
         if (!r) HD_FAIL(c, HD_ERR_WEIGHTS, "Missing key in state_dict: %s", e.first.c_str());
@@ -1050,7 +1060,7 @@ int hd_finalize_weights(hd_ctx* c) {
     }
     c->film_total = off;
     off = 0;
-    for (int l = 0; l < 4; ++l)
+    for (int l = 0; l < 4 && c->conditional; ++l)
         for (int j = 0; j < enc[l]; ++j) {
             BlockW bw;
             rc = load_block("fpg.encoders." + std::to_string(l) + "." + std::to_string(j), WIDTH << l, bw);
@@ -1062,7 +1072,7 @@ int hd_finalize_weights(hd_ctx* c) {
     const int fpg_film_total = off;
     // ---- FiLM: concatenated Linear(256,4C) weights/biases, LN affine in table layout ----
     rc |= dev_alloc(c, &c->film_W, (size_t)c->film_total * FILM_IN); rc |= dev_alloc(c, &c->film_b, c->film_total);
-    rc |= dev_alloc(c, &c->ln_pack, c->film_total); rc |= dev_alloc(c, &c->fpg_ln_pack, fpg_film_total);
+    rc |= dev_alloc(c, &c->ln_pack, c->film_total); rc |= dev_alloc(c, &c->fpg_ln_pack, fpg_film_total + 4);
     rc |= dev_alloc(c, &c->film_blocks_dev, c->den_blocks.size());
     if (rc) return rc;
     std::vector<FilmBlock> fbs;
@@ -1083,7 +1093,8 @@ int hd_finalize_weights(hd_ctx* c) {
     HIPCHECK(c, hipMemcpy(c->film_blocks_dev, fbs.data(), fbs.size() * sizeof(FilmBlock), hipMemcpyHostToDevice));
     // ---- intro / ending weights re-laid for coalesced per-lane loads ----
     {
-        const RawTensor *iw = find_raw(c, "denoiser.intro.weight"), *fw = find_raw(c, "fpg.intro.weight"), *ew = find_raw(c, "denoiser.ending.weight");
+        const RawTensor *iw = find_raw(c, "denoiser.intro.weight"), *ew = find_raw(c, "denoiser.ending.weight");
+        const RawTensor* fw = c->conditional ? find_raw(c, "fpg.intro.weight") : iw;
         if (!iw || !fw || !ew) HD_FAIL(c, HD_ERR_INVALID, "intro/ending weights missing");
         rc |= dev_alloc(c, &c->intro_wT, 36 * 128); rc |= dev_alloc(c, &c->fpg_intro_wT, 36 * 128); rc |= dev_alloc(c, &c->ending_wT, 9 * 4 * 128);
         if (rc) return rc;
@@ -1096,13 +1107,13 @@ int hd_finalize_weights(hd_ctx* c) {
     for (int i = 0; i < 4; ++i) {
         rc |= pack_weight(c, "denoiser.downs." + std::to_string(i), &c->den_down[i]);
         { PackOpts o; o.S2 = 4; rc |= pack_weight(c, "denoiser.ups." + std::to_string(i) + ".0", &c->den_up[i], o); }   // sub-pixel major (EpPixShufF32)
-        rc |= pack_weight(c, "fpg.downs." + std::to_string(i), &c->fpg_down[i]);
+        if (c->conditional) rc |= pack_weight(c, "fpg.downs." + std::to_string(i), &c->fpg_down[i]);
     }
-    for (int i = 0; i < 5; ++i) { PackOpts o; o.S2 = i ? 4 : 1; rc |= pack_weight(c, "fpg.convs." + std::to_string(i) + ".0", &c->fpg_convs[i], o); }
-    { PackOpts o; o.S2 = c->S * c->S; rc |= pack_weight(c, "denoiser.idc_conv", &c->idc_conv, o); }
+    for (int i = 0; i < 5 && c->conditional; ++i) { PackOpts o; o.S2 = i ? 4 : 1; rc |= pack_weight(c, "fpg.convs." + std::to_string(i) + ".0", &c->fpg_convs[i], o); }
+    if (c->conditional) { PackOpts o; o.S2 = c->S * c->S; rc |= pack_weight(c, "denoiser.idc_conv", &c->idc_conv, o); }
     if (rc) return rc;
     // ---- HCAs ----
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 5 && c->conditional; ++i) {
         HcaW& h = c->hca[i];
         const std::string p = "denoiser.hcas." + std::to_string(i);
         h.C = (WIDTH << 4) >> i;
@@ -1128,9 +1139,9 @@ int hd_finalize_weights(hd_ctx* c) {
         r.cin = cin; r.cout = cout; r.k = k; r.stride = stride; r.pad = pad;
         return pack_weight(c, conv, &r.w, o);
     };
-    rc = load_res("idc.conv1", "idc.batch_norm1", 3, 64, 7, 2, 3, c->res_conv1);
+    if (c->conditional) rc = load_res("idc.conv1", "idc.batch_norm1", 3, 64, 7, 2, 3, c->res_conv1);
     if (rc) return rc;
-    {
+    if (c->conditional) {
         const int res_layers[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
         int cin = 64;
         for (int li = 0; li < 4; ++li)
@@ -1170,7 +1181,7 @@ int hd_finalize_weights(hd_ctx* c) {
             add_w(c->den_down[l], hwd);
             add_w(c->den_up[l], (double)(c->L >> (4 - l)) * (c->L >> (4 - l)));
         }
-        for (int i = 0; i < 5; ++i) { const double hw = (double)(c->L >> (4 - i)) * (c->L >> (4 - i)); add_w(c->hca[i].fused, hw); }
+        for (int i = 0; i < 5 && c->conditional; ++i) { const double hw = (double)(c->L >> (4 - i)) * (c->L >> (4 - i)); add_w(c->hca[i].fused, hw); }
         params += 2 * 128 * 36; macs += 2.0 * c->L * c->L * 128 * 36;
     }
     c->weight_bytes_per_step = params * 2;
@@ -1194,7 +1205,21 @@ static int prepare_common(hd_ctx* c, int batch) {
     return alloc_workspace(c, batch);
 }
 
+#define HD_NEED_CONDITIONAL(c, what) \
+    do { if ((c) && !(c)->conditional) HD_FAIL(c, HD_ERR_INVALID, what ": this context holds the unconditional Denoiser (no priors / identity)"); } while (0)
+
+// Unconditional Denoiser: nothing to condition on -- size the workspace for `batch` faces and build the launch program.
+int hd_prepare_unconditional(hd_ctx* c, int batch, void* stream) {
+    (void)stream;
+    if (c && c->conditional) HD_FAIL(c, HD_ERR_INVALID, "hd_prepare_unconditional: this context holds the conditional FusedDenoiser");
+    int rc = prepare_common(c, batch);
+    if (rc) return rc;
+    c->prepared = true;
+    return HD_OK;
+}
+
 int hd_prepare(hd_ctx* c, int batch, const float* cr_latent, const float* cr_face, const float* id_emb, void* stream) {
+    HD_NEED_CONDITIONAL(c, "hd_prepare");
     int rc = prepare_common(c, batch);
     if (rc) return rc;
     if (!cr_latent || (!cr_face == !id_emb)) HD_FAIL(c, HD_ERR_INVALID, "need cr_latent and exactly one of cr_face / id_emb");
@@ -1219,6 +1244,7 @@ int hd_prepare(hd_ctx* c, int batch, const float* cr_latent, const float* cr_fac
 }
 
 int hd_prepare_from_priors(hd_ctx* c, int batch, const float* const priors[5], const float* id_emb, void* stream) {
+    HD_NEED_CONDITIONAL(c, "hd_prepare_from_priors");
     int rc = prepare_common(c, batch);
     if (rc) return rc;
     if (!priors || !id_emb) HD_FAIL(c, HD_ERR_INVALID, "priors and id_emb are required");
@@ -1247,6 +1273,7 @@ int hd_prepare_from_priors(hd_ctx* c, int batch, const float* const priors[5], c
 }
 
 int hd_fpg(hd_ctx* c, int batch, const float* cr_latent, float* const priors_out[5], void* stream) {
+    HD_NEED_CONDITIONAL(c, "hd_fpg");
     int rc = prepare_common(c, batch);
     if (rc) return rc;
     if (!cr_latent || !priors_out) HD_FAIL(c, HD_ERR_INVALID, "hd_fpg: bad arguments");
@@ -1273,6 +1300,7 @@ int hd_fpg(hd_ctx* c, int batch, const float* cr_latent, float* const priors_out
 }
 
 int hd_idc(hd_ctx* c, int batch, const float* cr_face, float* id_emb_out, void* stream) {
+    HD_NEED_CONDITIONAL(c, "hd_idc");
     int rc = prepare_common(c, batch);
     if (rc) return rc;
     if (!cr_face || !id_emb_out) HD_FAIL(c, HD_ERR_INVALID, "hd_idc: bad arguments");

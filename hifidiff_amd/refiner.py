@@ -47,8 +47,9 @@ def _f32c(t, device):
 class _Engine:
     """Owns the hd_ctx of one (latent_res, device)."""
 
-    def __init__(self, latent_res):
+    def __init__(self, latent_res, conditional=True):
         self.latent_res = int(latent_res)
+        self.conditional = conditional     # False: the unconditional Denoiser (models/denoiser/model.py:32)
         self.ctx = None
         self.device = None
         self.state = None          # CPU copy of the loaded state dict (for state_dict())
@@ -65,20 +66,29 @@ class _Engine:
             if idx != self.device.index:
                 raise RuntimeError("this model already lives on cuda:%d" % self.device.index)
             return
-        L = _lib.lib()
-        ctx = ctypes.c_void_p()
-        _lib.check(L.hd_create(ctypes.byref(ctx), self.latent_res, idx))
+        ctx = self._create(idx)
         self.ctx, self.device = ctx, torch.device("cuda", idx)
         if self.state is not None:
             self._upload()
 
+    def _create(self, idx):
+        L = _lib.lib()
+        ctx = ctypes.c_void_p()
+        _lib.check((L.hd_create if self.conditional else L.hd_create_unconditional)(ctypes.byref(ctx), self.latent_res, idx))
+        return ctx
+
+    def manifest(self):
+        if self.conditional:
+            return arch.refiner_manifest(self.latent_res)
+        return arch.denoiser_manifest(self.latent_res, prefix="denoiser", fused=False)
+
     def load(self, sd, strict=True):
-        man = arch.refiner_manifest(self.latent_res)
+        man = self.manifest()
         missing = [k for k in man if k not in sd]
         unexpected = [k for k in sd if k not in man]
         if strict and (missing or unexpected):
-            raise RuntimeError("Error(s) in loading state_dict for FacialRefiner: Missing key(s): %s; Unexpected key(s): %s"
-                               % (missing[:4], unexpected[:4]))
+            raise RuntimeError("Error(s) in loading state_dict for %s: Missing key(s): %s; Unexpected key(s): %s"
+                               % ("FacialRefiner" if self.conditional else "Denoiser", missing[:4], unexpected[:4]))
         for k, (shape, _, _) in man.items():
             if k in sd and tuple(sd[k].shape) != tuple(shape):
                 raise RuntimeError("size mismatch for %s: got %s, expected %s" % (k, tuple(sd[k].shape), tuple(shape)))
@@ -90,7 +100,7 @@ class _Engine:
         return missing, unexpected
 
     def _upload(self):
-        man = arch.refiner_manifest(self.latent_res)
+        man = self.manifest()
         if any(k not in self.state for k in man):
             raise RuntimeError("state dict incomplete: %d of %d tensors loaded" % (len(self.state), len(man)))
         L = _lib.lib()
@@ -110,9 +120,7 @@ class _Engine:
             d.is_device = 1 if t.is_cuda else 0
         if self.loaded:      # re-load: a fresh context is simplest (weights are packed once)
             L.hd_destroy(self.ctx)
-            ctx = ctypes.c_void_p()
-            _lib.check(L.hd_create(ctypes.byref(ctx), self.latent_res, self.device.index))
-            self.ctx = ctx
+            self.ctx = self._create(self.device.index)
         with torch.cuda.device(self.device):
             _lib.check(L.hd_load_weights(self.ctx, descs, len(man)), self.ctx)
             _lib.check(L.hd_finalize_weights(self.ctx), self.ctx)
@@ -140,6 +148,13 @@ class _Engine:
             _lib.check(_lib.lib().hd_prepare(self.ctx, B, crl.data_ptr(), crf.data_ptr() if crf is not None else None,
                                              emb.data_ptr() if emb is not None else None, _stream(self.device)), self.ctx)
         self.batch = B
+
+    def prepare_unconditional(self, batch):
+        self.require_loaded()
+        if self.batch != batch:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().hd_prepare_unconditional(self.ctx, batch, _stream(self.device)), self.ctx)
+            self.batch = batch
 
     def prepare_from_priors(self, priors, id_emb):
         self.require_loaded()
@@ -245,6 +260,50 @@ class FusedDenoiser(_SubModule):
         e = self._engine
         e.ensure(latents.device)
         e.prepare_from_priors(facial_priors, identity_embedding)
+        return UNet2DOutput(e.eps(latents, timesteps))
+
+
+class Denoiser(nn.Module):
+    """The unconditional pre-training network (models/denoiser/model.py:32-134): `model(latents, t).sample`, as the
+    sampling loop of pretrain_denoiser.py:101-110 calls it.  State-dict keys are the reference's (no prefix)."""
+
+    def __init__(self, latent_size):
+        super().__init__()
+        if latent_size % 16 != 0 or latent_size < 16:
+            raise ValueError("latent_size must be a multiple of 16")
+        object.__setattr__(self, "_engine", _Engine(latent_size, conditional=False))
+        self.width = 32 * 4
+        self.dtype = torch.float32
+        self.config = _Config()
+        self.config.in_channels = 4
+        self.config.sample_size = latent_size
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing, unexpected = self._engine.load({"denoiser." + k: v for k, v in state_dict.items()}, strict)
+        n = len("denoiser.")
+        return torch.nn.modules.module._IncompatibleKeys([k[n:] for k in missing], [k[n:] for k in unexpected])
+
+    def state_dict(self, *a, **k):
+        n = len("denoiser.")
+        return {key[n:]: v for key, v in (self._engine.state or {}).items()}
+
+    def to(self, *args, **kwargs):
+        device = kwargs.get("device", args[0] if args else None)
+        if isinstance(device, (str, torch.device, int)):
+            self._engine.ensure(torch.device("cuda", device) if isinstance(device, int) else device)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def forward(self, latents, timesteps):
+        e = self._engine
+        e.ensure(latents.device)
+        e.prepare_unconditional(latents.shape[0])
         return UNet2DOutput(e.eps(latents, timesteps))
 
 

@@ -26,13 +26,31 @@ def ddim_sample_eager(model, latents, cr_face, cr_latent, scheduler, num_inferen
 
 
 @torch.no_grad()
+def ddim_sample_eager_unconditional(model, latents, scheduler, num_inference_steps=50):
+    """The unconditional loop of pretrain_denoiser.py:99-110 against the mirrored `Denoiser`."""
+    bs = latents.shape[0]
+    scheduler.set_timesteps(num_inference_steps, device=latents.device)
+    for t in scheduler.timesteps:
+        t_batch = torch.full((bs,), int(t), device=latents.device, dtype=torch.long)
+        noise_pred = model(latents, t_batch).sample
+        latents = scheduler.step(noise_pred, t, latents, eta=0.0).prev_sample
+    return latents
+
+
+@torch.no_grad()
 def sample(model, latents, cr_face, cr_latent, scheduler, noise=None, seed=0, prepare=True):
     """Whole loop on the GPU: returns the final latents (a new tensor).
 
-    noise: optional [n_steps, B, 4, L, L] tensor of z (DDPM); None -> device Philox(seed)."""
+    noise: optional [n_steps, B, 4, L, L] tensor of z (DDPM); None -> device Philox(seed).
+    For the unconditional `Denoiser` pass cr_face = cr_latent = None."""
     e = model.engine
     e.ensure(latents.device)
-    if prepare:
+    if not e.conditional:
+        if cr_face is not None or cr_latent is not None:
+            raise RuntimeError("the unconditional Denoiser takes no cr_face / cr_latent")
+        e.require_loaded()
+        e.prepare_unconditional(latents.shape[0])
+    elif prepare:
         model.prepare(cr_face, cr_latent)
     e.require_loaded()
     x = latents.to(device=e.device, dtype=torch.float32).contiguous().clone()

@@ -55,6 +55,11 @@ typedef struct hd_schedule {
 /* FacialRefiner(latent_res) (models/refiner.py:11-16): builds the network description for latent
  * side `latent_res` (16 for 16->128 px, 32 for 32->256 px) on HIP device `device`. */
 int hd_create(hd_ctx** out, int latent_res, int device);
+/* The unconditional pre-training network `Denoiser(latent_size)` (models/denoiser/model.py:32-134; sampled by
+ * pretrain_denoiser.py:76-120): the same UNet without priors, HCAs and identity term.  Its state-dict keys are
+ * passed with the prefix "denoiser." (denoiser.time_mlp.1.weight, denoiser.encoders.0.0.conv1.weight ...).
+ * Use hd_prepare_unconditional instead of hd_prepare; hd_eps / hd_sample work as for the refiner. */
+int hd_create_unconditional(hd_ctx** out, int latent_res, int device);
 void hd_destroy(hd_ctx* ctx);
 const char* hd_last_error(const hd_ctx* ctx);   /* ctx may be NULL: creation errors */
 
@@ -72,6 +77,9 @@ int hd_finalize_weights(hd_ctx* ctx);
  *   cr_face / id_emb must be given: id_emb is what FusedDenoiser.forward receives directly). */
 int hd_prepare(hd_ctx* ctx, int batch, const float* cr_latent, const float* cr_face,
                const float* id_emb, void* stream);
+/* Unconditional Denoiser: `model(latents, t)` has nothing to hoist; this sizes the workspace for `batch`
+ * latents and builds the launch program (pretrain_denoiser.py:101-110). */
+int hd_prepare_unconditional(hd_ctx* ctx, int batch, void* stream);
 
 /* Same, but from already-computed priors: FusedDenoiser.forward(latents, timesteps, facial_priors,
  * identity_embedding) (models/denoiser/model.py:217).  priors[i] is NCHW

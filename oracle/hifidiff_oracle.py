@@ -326,6 +326,33 @@ def fused_denoiser(P, latents, timesteps, priors=None, id_emb=None, prec=FP32, p
     return x
 
 
+def denoiser_uncond(P, latents, timesteps, prec=FP32, prefix="denoiser", taps=None):
+    """Denoiser.forward (models/denoiser/model.py:112-134): the UNet without priors, HCAs and identity term."""
+    p = prefix
+    B = latents.shape[0]
+    t = normalize_timesteps(timesteps, B)
+    temb = time_embedding(P, t, p)
+    x = F.conv2d(latents, P[p + ".intro.weight"], P[p + ".intro.bias"], padding=1)
+    _tap(taps, "intro", x)
+    skips = []
+    for i, n in enumerate((2, 2, 4, 8)):
+        for j in range(n):
+            x = cond_naf_block(P, f"{p}.encoders.{i}.{j}", x, temb, prec, taps)
+        skips.append(x)
+        x = _gemm_conv(x, P[f"{p}.downs.{i}.weight"], P[f"{p}.downs.{i}.bias"], prec, stride=2)
+        _tap(taps, f"downs.{i}", x)
+    for j in range(8):
+        x = cond_naf_block(P, f"{p}.middle_blks.{j}", x, temb, prec, taps)
+    for i, skip in enumerate(skips[::-1]):
+        x = _up_shuffle(x, P[f"{p}.ups.{i}.0.weight"], 2, prec) + skip
+        _tap(taps, f"ups.{i}", x)
+        for j in range(2):
+            x = cond_naf_block(P, f"{p}.decoders.{i}.{j}", x, temb, prec, taps)
+    x = F.conv2d(x, P[p + ".ending.weight"], P[p + ".ending.bias"], padding=1)
+    _tap(taps, "ending", x)
+    return x
+
+
 def refiner_forward(P, latents, timesteps, cr_face, cr_latent, prec=FP32):
     """FacialRefiner.forward as written: FPG and IDC recomputed on every call (models/refiner.py:32-38)."""
     priors = fpg(P, cr_latent, "fpg", prec)

@@ -54,14 +54,48 @@ def T(a):
 
 
 @torch.no_grad()
+def gen_uncond(args):
+    """Unconditional `Denoiser(16)` (models/denoiser/model.py:32-134): eps at three timesteps and a 10-step DDIM
+    (pretrain_denoiser.py:76-120 loop body inside the restated scheduler).  Weights: the `denoiser.*` tensors of the
+    synthetic refiner state dict that the Denoiser has (no hcas / idc_conv)."""
+    import_reference(args.ref)
+    from models.denoiser.model import Denoiser
+    man = arch.denoiser_manifest(16, prefix="denoiser", fused=False)
+    sd = {k[len("denoiser."):]: torch.from_numpy(v) if isinstance(v, np.ndarray) else v
+          for k, v in synth.make_state_dict(man).items()}
+    net = Denoiser(16).eval()
+    net.load_state_dict(sd, strict=True)
+    B = 2
+    x = T(np.stack([synth.randn(f"x_T/{f}", (4, 16, 16)) for f in range(B)]))
+    out = {}
+    for i, t in enumerate([(980, 980), (500, 20), (0, 0)]):
+        tt = torch.tensor(t)
+        out[f"t{i}"] = tt.numpy()
+        out[f"eps{i}"] = net(x, tt).sample.numpy()
+    out["eps_scalar_t"] = net(x, 321).sample.numpy()           # python scalar timestep (model.py:113-114)
+    sch = O.DDIMScheduler(clip_sample=True, clip_sample_range=3.0)
+    sch.set_timesteps(10)
+    lat = x.clone()
+    for t in sch.timesteps:
+        eps = net(lat, torch.full((B,), int(t))).sample
+        lat = sch.step(eps, int(t), lat).prev_sample
+    out["ddim10"] = lat.numpy()
+    np.savez_compressed(os.path.join(args.out, "denoiser_uncond_L16.npz"), **out)
+    print("wrote denoiser_uncond_L16.npz", {k: v.shape for k, v in out.items()})
+
+
+@torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-l32", action="store_true")
+    ap.add_argument("--only", default="", help="'uncond': only the unconditional Denoiser fixture")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
+    if args.only == "uncond":
+        return gen_uncond(args)
     FacialRefiner, CondBlock, PosEmb, HCA = import_reference(args.ref)
 
     t0 = time.time()

@@ -237,3 +237,60 @@ def test_error_behaviour(gpu, weights16, model2, inputs2):
     m2.to("cuda:0")
     with pytest.raises(RuntimeError):
         m2(x, 0, crf, crl)                                         # weights never loaded
+
+
+def test_unconditional_denoiser_against_reference_golden(gpu, weights16):
+    """the pre-training `Denoiser` (no priors / HCAs / identity) through the same kernels:
+    eps vs the reference's outputs and the emulating oracle, the reference's loop body (eager) and the graph loop."""
+    from hifidiff_amd import sampling, schedulers, synth
+    from hifidiff_amd.refiner import Denoiser
+    from oracle import hifidiff_oracle as O
+    g = golden("denoiser_uncond_L16.npz")
+    m = Denoiser(16)
+    n = len("denoiser.")
+    sd = {k[n:]: v for k, v in weights16.items() if k.startswith("denoiser.") and ".hcas." not in k and ".idc_conv" not in k}
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**sd, "hcas.0.fused_mlp.0.weight": torch.zeros(1)})     # strict: unexpected key
+    m.load_state_dict(sd)
+    m.to("cuda:0")
+    x = T(np.stack([synth.randn(f"x_T/{f}", (4, 16, 16)) for f in range(2)]))
+    for i in range(3):
+        e = m(x.cuda(), T(g[f"t{i}"]).cuda()).sample.cpu()
+        assert rel_l2(e, g[f"eps{i}"]) <= 1e-2, i
+    assert rel_l2(m(x.cuda(), 321).sample.cpu(), g["eps_scalar_t"]) <= 1e-2
+    e = m(x.cuda(), T(g["t1"]).cuda()).sample.cpu()
+    assert rel_l2(e, O.denoiser_uncond(weights16, x, T(g["t1"]), prec=O.BF16)) <= 6e-3
+    sch = schedulers.DDIMScheduler(clip_sample_range=3.0)
+    eager = sampling.ddim_sample_eager_unconditional(m, x.cuda(), sch, 10).cpu()
+    sch.set_timesteps(10)
+    graph = sampling.sample(m, x.cuda(), None, None, sch).cpu()
+    assert psnr(eager, g["ddim10"]) >= 40.0 and psnr(graph, g["ddim10"]) >= 40.0, (psnr(eager, g["ddim10"]), psnr(graph, g["ddim10"]))
+    with pytest.raises(RuntimeError):
+        sampling.sample(m, x.cuda(), x.cuda(), x.cuda(), sch)      # no conditioning inputs in this mode
+
+
+def test_checkpoint_ingest(gpu, weights16, model2, inputs2, tmp_path):
+    """a `model.safetensors` as accelerate's save_state writes it (test_refiner.py:162-164) and the
+    constructor's idc .pt / denoiser .safetensors pair (models/refiner.py:18-25) load to the same packed weights."""
+    from safetensors.torch import load_file, save_file
+    from hifidiff_amd.refiner import FacialRefiner
+    x, crl, crf = [t.cuda() for t in inputs2]
+    want = model2(x, 500, crf, crl).sample.cpu()
+    path = str(tmp_path / "model.safetensors")
+    save_file({k: v.contiguous() for k, v in weights16.items()}, path)
+    m = FacialRefiner(latent_res=16)
+    m.load_state_dict(load_file(path))
+    m.to("cuda:0")
+    assert torch.equal(m(x, 500, crf, crl).sample.cpu(), want)
+    os.remove(path)
+    # constructor form: IDC from a .pt, denoiser (+ the FPG tensors it shares names with) from a .safetensors
+    idc_pt, den_st = str(tmp_path / "idc.pt"), str(tmp_path / "denoiser.safetensors")
+    torch.save({"model_state_dict": {k[4:]: v for k, v in weights16.items() if k.startswith("idc.")}}, idc_pt)
+    save_file({k[len("denoiser."):]: v.contiguous() for k, v in weights16.items() if k.startswith("denoiser.")}, den_st)
+    m3 = FacialRefiner(16, idc_ckpt=idc_pt, denoiser_ckpt=den_st)
+    sd = m3.state_dict()
+    assert all(torch.equal(sd[k], weights16[k]) for k in sd if k.startswith("idc.") or k.startswith("denoiser."))
+    # fpg.* came from the denoiser's same-named encoder tensors (refiner.py:23-24, strict=False)
+    assert torch.equal(sd["fpg.encoders.0.0.conv1.weight"], weights16["denoiser.encoders.0.0.conv1.weight"])
+    with pytest.raises(RuntimeError):
+        m3.to("cuda:0")                                             # fpg.convs.* have no source yet: state dict incomplete

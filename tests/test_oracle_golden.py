@@ -110,3 +110,13 @@ def test_scheduler_formulas():
         x0 = ((x - c[i, 0] * e) / c[i, 1]).clamp(-c[i, 2], c[i, 2])
         got = c[i, 3] * x0 + c[i, 4] * x + c[i, 5] * e + c[i, 6] * z
         assert torch.allclose(got, ref, atol=2e-5)
+
+
+def test_unconditional_denoiser(weights16):
+    """`Denoiser` (models/denoiser/model.py:32-134) restated, against the reference's own outputs."""
+    g = golden("denoiser_uncond_L16.npz")
+    x = torch.from_numpy(np.stack([synth.randn(f"x_T/{f}", (4, 16, 16)) for f in range(2)]))
+    for i in range(3):
+        assert rel_l2(O.denoiser_uncond(weights16, x, torch.from_numpy(g[f"t{i}"])), g[f"eps{i}"]) <= TOL32, i
+    assert rel_l2(O.denoiser_uncond(weights16, x, 321), g["eps_scalar_t"]) <= TOL32
+    assert rel_l2(O.denoiser_uncond(weights16, x, torch.from_numpy(g["t1"]), prec=O.BF16), g["eps1"]) <= 1e-2
