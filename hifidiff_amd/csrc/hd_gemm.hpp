@@ -178,6 +178,7 @@ struct LdF32Plain {
     template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
     template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
+    template <class S> static __device__ __forceinline__ void unit_stats(S&, int, const char*) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
         st.rowp = reinterpret_cast<const float*>(p.A) + (size_t)(st.valid ? row : 0) * p.lda;
@@ -263,36 +264,33 @@ struct LdF32LN {
             }
         }
         if (fast<BM, THREADS>(p)) {
+            // all partials of a row cover the same number of channels, so the exact decomposition
+            //   mean = sum(mean_i) / np,   M2 = sum(M2_i + cnt * (mean_i - mean)^2)
+            // needs two short sums (own partials, then a DPP butterfly over the row's TPR lanes: lane^1, lane^2,
+            // half-row mirror, row mirror) instead of Chan's pairwise updates with their divisions -- this runs
+            // on every thread of every LayerNorm GEMM, two waves per SIMD, ahead of the first MFMA.
             const int rl = tid / TPR, part = tid % TPR;
+            auto row_sum = [](float v) {
+                if (TPR > 1) v += dpp_mov<0xB1>(v);
+                if (TPR > 2) v += dpp_mov<0x4E>(v);
+                if (TPR > 4) v += dpp_mov<0x141>(v);
+                if (TPR > 8) v += dpp_mov<0x140>(v);
+                return v;
+            };
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < kPP; ++i) sm += pre.s[i].y >= 0.f ? pre.s[i].x : 0.f;
+            const float inv_np = 1.0f / (float)p.stats_np;               // wave-uniform (scalar unit)
+            const float mean = row_sum(sm) * inv_np;
             const float cnt = (float)p.stats_cnt;
-            float n = 0.f, mean = 0.f, m2 = 0.f;
+            float q = 0.f;
 #pragma unroll
             for (int i = 0; i < kPP; ++i) {
-                if (pre.s[i].y >= 0.f) {
-                    const float d = pre.s[i].x - mean, nn = n + cnt;
-                    mean += d * (cnt / nn);
-                    m2 += pre.s[i].y + d * d * (n * cnt / nn);
-                    n = nn;
-                }
+                const float d = pre.s[i].x - mean;
+                q += pre.s[i].y >= 0.f ? fmaf(cnt * d, d, pre.s[i].y) : 0.f;
             }
-#pragma unroll
-            for (int o = 1; o < TPR; o <<= 1) {      // butterfly: lane^1, lane^2, half-row mirror, row mirror
-                const float n2 = o == 1 ? dpp_mov<0xB1>(n) : o == 2 ? dpp_mov<0x4E>(n) : o == 4 ? dpp_mov<0x141>(n) : dpp_mov<0x140>(n);
-                const float mean2 = o == 1 ? dpp_mov<0xB1>(mean) : o == 2 ? dpp_mov<0x4E>(mean) : o == 4 ? dpp_mov<0x141>(mean) : dpp_mov<0x140>(mean);
-                const float m22 = o == 1 ? dpp_mov<0xB1>(m2) : o == 2 ? dpp_mov<0x4E>(m2) : o == 4 ? dpp_mov<0x141>(m2) : dpp_mov<0x140>(m2);
-                // the pair (lower lane group, upper lane group) is always merged in that order
-                const bool hi = (part & o) != 0;
-                const float na = hi ? n2 : n, nb = hi ? n : n2;
-                const float ma = hi ? mean2 : mean, mb = hi ? mean : mean2;
-                const float nn = na + nb;
-                if (nn > 0.f) {
-                    const float d = mb - ma;
-                    m2 = m2 + m22 + d * d * (na * nb / nn);
-                    mean = ma + d * (nb / nn);
-                    n = nn;
-                }
-            }
-            if (part == 0 && rl < BM) st[rl] = make_float2(mean, n > 0.f ? 1.0f / sqrtf(m2 / n + p.ln_eps) : 0.f);
+            const float var = row_sum(q) * (inv_np / cnt);
+            if (part == 0 && rl < BM) st[rl] = make_float2(mean, (row0 + rl < p.M) ? __frsqrt_rn(var + p.ln_eps) : 0.f);
         } else {
             for (int base = 0; base < BM; base += THREADS / 4) {
                 const int rl = base + (tid >> 2), part = tid & 3;
@@ -336,13 +334,16 @@ struct LdF32LN {
         st.valid = row < p.M;
         const int r = st.valid ? row : 0;
         st.rowp = reinterpret_cast<const unsigned short*>(p.A) + (size_t)r * p.lda;
-        const float2 s = reinterpret_cast<const float2*>(stats)[row_local];
-        st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
+        st.mu = 0.f; st.rstd = 0.f;                                  // filled by unit_stats() after block_finish()
         st.gbl = (gb && p.film_face_stride == 0) ? gb : nullptr;      // LDS copy of the shared FiLM row
-        const int step = p.step_ptr ? *p.step_ptr : 0;
-        const float* f = p.film + (size_t)step * p.film_step_stride + (size_t)(p.face0 + r / p.hw) * p.film_face_stride;
+        const float* f = film_row(p);
+        if (p.film_face_stride != 0) f += (size_t)(p.face0 + r / p.hw) * p.film_face_stride;   // per-face timesteps (wave-uniform test)
         st.gain = f + p.film_gain_off;
         st.bias = f + p.film_bias_off;
+    }
+    static __device__ __forceinline__ void unit_stats(St& st, int row_local, const char* stats) {
+        const float2 s = reinterpret_cast<const float2*>(stats)[row_local];
+        st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
     }
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
         r.x = (st.valid && kc < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
@@ -374,6 +375,7 @@ struct LdBF16Plain {
     template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
     template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
+    template <class S> static __device__ __forceinline__ void unit_stats(S&, int, const char*) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
         st.rowp = reinterpret_cast<const unsigned short*>(p.A) + (size_t)(st.valid ? row : 0) * p.lda;
@@ -394,6 +396,7 @@ struct LdBF16Scale {
     template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
     template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
+    template <class S> static __device__ __forceinline__ void unit_stats(S&, int, const char*) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
         const int r = st.valid ? row : 0;
@@ -429,6 +432,7 @@ struct LdConv {
     template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
     template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
     template <int BM, int THREADS> static __device__ void block_init(const GemmP&, int, char*, float*, int) {}
+    template <class S> static __device__ __forceinline__ void unit_stats(S&, int, const char*) {}
     static __device__ __forceinline__ void unit_init(const GemmP& p, St& st, int row, int, const char*, const float*) {
         st.valid = row < p.M;
         const int r = st.valid ? row : 0;
@@ -741,13 +745,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
     HD_LOAD_B(bcur, 0);
     // the loads above do not depend on the LayerNorm statistics; merge them while the loads fly
     LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
-    if (LD::kGainBiasLds) {
 #pragma unroll
-        for (int u = 0; u < C::UNITS; ++u) {
-            const int rl = (tid >> 3) + u * (C::THREADS / 8);
-            LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
-        }
-    }
+    for (int u = 0; u < C::UNITS; ++u) LD::unit_stats(st[u], (tid >> 3) + u * (C::THREADS / 8), smem + C::STATS_OFF);
     HD_STAMP(1);
     HD_WRITE_A(0, 0);
     __syncthreads();
@@ -980,14 +979,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         LD::fetch(p, st[u], ((chunk) < c_end) ? (chunk) * BK : p.Kp, kq, aq[slot][u]);
 #pragma unroll
     for (int d = 0; d < D; ++d) { HD_SK_FETCH_A(d, c0 + d); }
+    HD_STAMP(6);
     LD::template block_finish<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid, pre);
-    if (LD::kGainBiasLds) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int rl = wm * C::WROWS + (lane >> 3) + 8 * u;
-            LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
-        }
-    }
+    for (int u = 0; u < UN; ++u) LD::unit_stats(st[u], wm * C::WROWS + (lane >> 3) + 8 * u, smem + C::STATS_OFF);
     HD_STAMP(1);
 
     char* sA = smem + wave * C::A_WAVE;

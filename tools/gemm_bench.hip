@@ -67,12 +67,15 @@ static void report_stamps(unsigned long long* dev, int nwg) {
     printf("  | span %.2f us, start skew %.2f;", (double)(t5 - t0) * 0.01, first_last_start);
     const char* nm[5] = {"issue", "1st-chunk", "rest-K", "sync", "epi"};
     for (int i = 0; i < 5; ++i) { std::sort(d[i].begin(), d[i].end()); printf(" %s %.2f/%.2f", nm[i], d[i][d[i].size() / 2], d[i].back()); }
+    { std::vector<double> q; for (int w = 0; w < nwg; ++w) if (h[(size_t)w * 8 + 6]) q.push_back((double)(h[(size_t)w * 8 + 6] - h[(size_t)w * 8]) * 0.01);
+      if (!q.empty()) { std::sort(q.begin(), q.end()); printf(" | loads-issued@ %.2f/%.2f", q[q.size() / 2], q.back()); } }
     printf("\n");
 }
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 64, K = argc > 2 ? atoi(argv[2]) : 2048, N = argc > 3 ? atoi(argv[3]) : 2048;
     const int iters = 200;
+    const int LDA = K + (getenv("LDA_PAD") ? atoi(getenv("LDA_PAD")) : 0);     // leading dimension of A in elements
     hipStream_t s; CK(hipStreamCreate(&s));
     const size_t wbytes = (size_t)N * K * 2;
     const int nrot = (int)((700ull << 20) / wbytes) + 1;
@@ -97,7 +100,7 @@ int main(int argc, char** argv) {
 
     auto base = [&](int i) {
         GemmP p{};
-        p.M = M; p.N = N; p.K = K; p.Kp = K; p.nt_total = N / 32; p.W = b.W[i % nrot];
+        p.M = M; p.N = N; p.K = K; p.Kp = K; p.nt_total = N / 32; p.W = b.W[getenv("NOROT") ? 0 : i % nrot];
         p.a_scale = 1.f; p.hw = 1; p.ln_eps = 1e-6f; p.shuffle_r = 1; p.stats_np = NP; p.stats_cnt = K / NP;
         p.bias = b.bias; p.rscale = b.rscale; p.resid = b.resid; p.ldr = N; p.out = b.out; p.ldo = N;
         return p;
@@ -158,18 +161,18 @@ int main(int argc, char** argv) {
         printf("graph replay, 200 launches on one stream: %.2f us/launch; 2 x 200 on two streams: %.2f us per pair (%.2fx throughput)\n",
                one * 1000 / 200, two * 1000 / 200, 2 * one / two);
 
-        RUN_SK("skinny bf16plain resid MT1 W8 D4", 1, 8, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
-        RUN_SK("skinny bf16plain resid MT1 W8 D2", 1, 8, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
-        RUN_SK("skinny bf16plain resid MT1 W4 D4", 1, 4, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
-        RUN_SK("skinny bf16plain resid MT2 W8 D4", 2, 8, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
-        RUN_SK("skinny bf16plain resid MT2 W8 D2", 2, 8, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
+        RUN_SK("skinny bf16plain resid MT1 W8 D4", 1, 8, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
+        RUN_SK("skinny bf16plain resid MT1 W8 D2", 1, 8, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
+        RUN_SK("skinny bf16plain resid MT1 W4 D4", 1, 4, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
+        RUN_SK("skinny bf16plain resid MT2 W8 D4", 2, 8, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
+        RUN_SK("skinny bf16plain resid MT2 W8 D2", 2, 8, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
         RUN_SK("skinny f32plain bias  MT1 W8 D2", 1, 8, false, 2, LdF32Plain, EpBiasF32, (p.A = b.A, p.lda = K))
         RUN_SK("skinny f32plain bias  MT1 W8 D4", 1, 8, false, 4, LdF32Plain, EpBiasF32, (p.A = b.A, p.lda = K))
-        RUN_SK("skinny bf16scale resid MT1 W8 D2", 1, 8, false, 2, LdBF16Scale, EpResidF32, (p.A = Ab, p.lda = K, p.rowscale = b.rowscale))
-        RUN_SK("skinny LN bias MT1 W8 D2", 1, 8, false, 2, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
-        RUN_SK("skinny LN bias MT1 W8 D4", 1, 8, false, 4, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
-        RUN_SK("skinny LN gate(pair) MT1 W8 D2", 1, 8, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
-        RUN_SK("skinny LN gate(pair) MT2 W8 D1", 2, 8, true, 1, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny bf16scale resid MT1 W8 D2", 1, 8, false, 2, LdBF16Scale, EpResidF32, (p.A = Ab, p.lda = LDA, p.rowscale = b.rowscale))
+        RUN_SK("skinny LN bias MT1 W8 D2", 1, 8, false, 2, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
+        RUN_SK("skinny LN bias MT1 W8 D4", 1, 8, false, 4, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
+        RUN_SK("skinny LN gate(pair) MT1 W8 D2", 1, 8, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny LN gate(pair) MT2 W8 D1", 2, 8, true, 1, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
     }
 #define RUN_TALL(name, CFG, LD, EP, setup)                                                               \
     {                                                                                                    \
@@ -195,23 +198,23 @@ int main(int argc, char** argv) {
         float* dww; CK(hipMalloc(&dww, (size_t)N * 9 * 4)); hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, dww, (size_t)N * 9, 0.3f);
         const int hw = (M == 16384) ? 256 : 64, side = (M == 16384) ? 16 : 8;
         if (hw == 256) {
-            RUN_SKW("skinny WM8 LN dwgate (L0 conv1 fused)", 8, 1, 1, true, 1, LdF32LN, EpDwGate, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = hw, p.side = side))
-            RUN_SKW("skinny WM8 LN gate (no dw)", 8, 1, 1, true, 1, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.hw = hw))
-            RUN_SKW("skinny WM8 D2 LN gate (no dw)", 8, 1, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.hw = hw))
+            RUN_SKW("skinny WM8 LN dwgate (L0 conv1 fused)", 8, 1, 1, true, 1, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = hw, p.side = side))
+            RUN_SKW("skinny WM8 LN gate (no dw)", 8, 1, 1, true, 1, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.hw = hw))
+            RUN_SKW("skinny WM8 D2 LN gate (no dw)", 8, 1, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.hw = hw))
         } else {
-            RUN_SKW("skinny WM2 WK2 LN dwgate (L1 conv1 fused)", 2, 2, 1, true, 1, LdF32LN, EpDwGate, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = hw, p.side = side))
+            RUN_SKW("skinny WM2 WK2 LN dwgate (L1 conv1 fused)", 2, 2, 1, true, 1, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = hw, p.side = side))
         }
-        RUN_SKW("skinny WM4 bf16plain resid +stats", 4, 1, 1, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
-        RUN_SKW("skinny WM8 bf16plain resid +stats", 8, 1, 1, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
+        RUN_SKW("skinny WM4 bf16plain resid +stats", 4, 1, 1, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
+        RUN_SKW("skinny WM8 bf16plain resid +stats", 8, 1, 1, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
     }
     if (M >= 2048) {
-        RUN_TALL("tall T32W bf16plain resid", T32W, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
-        RUN_TALL("tall T32W bf16plain resid (no stats)", T32W, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K))
-        RUN_TALL("tall T64  bf16plain resid", T64, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
-        RUN_TALL("tall T128 bf16plain resid", T128, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = K, p.stats_out = b.stats_out))
-        RUN_TALL("tall T128 bf16scale resid", T128, LdBF16Scale, EpResidF32, (p.A = Ab, p.lda = K, p.rowscale = b.rowscale, p.hw = 256, p.stats_out = b.stats_out))
-        RUN_TALL("tall T128 LN bias", T128, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
-        RUN_TALL("tall T128P LN gate", T128P, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = K, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_TALL("tall T32W bf16plain resid", T32W, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
+        RUN_TALL("tall T32W bf16plain resid (no stats)", T32W, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
+        RUN_TALL("tall T64  bf16plain resid", T64, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
+        RUN_TALL("tall T128 bf16plain resid", T128, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
+        RUN_TALL("tall T128 bf16scale resid", T128, LdBF16Scale, EpResidF32, (p.A = Ab, p.lda = LDA, p.rowscale = b.rowscale, p.hw = 256, p.stats_out = b.stats_out))
+        RUN_TALL("tall T128 LN bias", T128, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
+        RUN_TALL("tall T128P LN gate", T128P, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
     }
     return 0;
 }
