@@ -82,6 +82,12 @@ struct GemmP {
     // SCA epilogue (EpScaBF16): rows of this GEMM are faces; scale_G[(face*scale_hw + r)][col] *= s in place
     unsigned short* scale_G;
     int scale_hw;
+    // next-kernel weight prefetch (skinny kernel): the packed tiles of the GEMM that runs after this one; tile t
+    // is consumed on XCD t % 8 (xcd_tile_affine map), so workgroups with linear id % 8 == x touch the tiles
+    // t % 8 == x and leave them in that XCD's L2.  NULL: nothing to prefetch.
+    const uint4* pf_base;
+    unsigned pf_tile_u4;          // uint4 per tile
+    int pf_ntiles;
 #ifdef HD_STAMPS
     unsigned long long* stamps;   // diagnostic build (tools/gemm_bench): [workgroup][8] s_memrealtime ticks (100 MHz)
 #endif
@@ -812,6 +818,29 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
 template <class EP, class = void> struct ep_is_sca_tile { static constexpr bool value = false; };
 template <class EP> struct ep_is_sca_tile<EP, decltype((void)EP::kScaTile)> { static constexpr bool value = EP::kScaTile; };
 
+// Touch this workgroup's share of the next GEMM's weight tiles so that they are in this XCD's L2 when that
+// kernel starts (its per-CU ingest is bound by the latency of the source: HBM ~2 us vs L2 ~0.6 us).  The loads
+// all target one 4-VGPR sink that stays reserved until prefetch_drain() at the end of the kernel; loads return
+// in order, so the extra (compiler-invisible) loads only ever make the compiler's own vmcnt waits stricter.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void prefetch_issue(const GemmP& p, int lin, int nwg, int tid, int nthreads, u32x4_t& sink) {
+    if (!p.pf_base) return;
+    const int x = lin & 7, r = lin >> 3, per_x = nwg >> 3;                 // nwg % 8 == 0 (caller)
+    const int tiles_x = (p.pf_ntiles - x + 7) >> 3;                          // tiles t = x, x+8, ...
+    if (tiles_x <= 0 || r >= per_x) return;
+    const unsigned total = (unsigned)tiles_x * p.pf_tile_u4;                 // uint4 units on this XCD (< 2^32: host)
+    const unsigned share = (total + per_x - 1) / per_x;
+    const unsigned lo = share * r, hi = (lo + share < total) ? lo + share : total;
+    for (unsigned i = lo + tid; i < hi; i += nthreads) {
+        const unsigned t = i / p.pf_tile_u4, o = i - t * p.pf_tile_u4;
+        const uint4* q = p.pf_base + ((size_t)(x + 8 * t) * p.pf_tile_u4 + o);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+    }
+}
+__device__ __forceinline__ void prefetch_drain(u32x4_t& sink) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
+}
+
 // ----------------------------------------------------------------------------------- skinny kernel
 // HALF: 16-row workgroup tiles (WM = MT = 1 only): at M = 64 this doubles the workgroups (4 row groups instead
 // of 2) so all 256 CUs pull weights; rows 16..31 of the MFMA tile stay zero in LDS.
@@ -979,6 +1008,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         LD::fetch(p, st[u], ((chunk) < c_end) ? (chunk) * BK : p.Kp, kq, aq[slot][u]);
 #pragma unroll
     for (int d = 0; d < D; ++d) { HD_SK_FETCH_A(d, c0 + d); }
+    u32x4_t pf_sink = {0u, 0u, 0u, 0u};
+    prefetch_issue(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y), tid, C::THREADS, pf_sink);
     HD_STAMP(6);
     LD::template block_finish<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid, pre);
 #pragma unroll
@@ -1155,6 +1186,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         if (full) skinny_rows_epilogue<true, C, EP>(p, red, row0, col, ncols, tile[0], tid);
         else skinny_rows_epilogue<false, C, EP>(p, red, row0, col, ncols, tile[0], tid);
     }
+    if (p.pf_base) prefetch_drain(pf_sink);
     HD_STAMP(5);
 }
 

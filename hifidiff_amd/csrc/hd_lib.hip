@@ -8,6 +8,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -62,6 +63,8 @@ enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE,
 struct Op {
     std::string name;
     std::function<hipError_t(hipStream_t)> run;
+    std::shared_ptr<GemmP> gemm;     // launch parameters of a GEMM op (patched by link_prefetch), else null
+    bool skinny_affine = false;      // runs in the skinny kernel with the XCD-affine tile map
     const void* out = nullptr;       // output buffer of the launch (introspection only)
     size_t out_elems = 0;
     int out_bf16 = 0;
@@ -429,16 +432,19 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
     Op op;
     op.name = name; op.out = p.out; op.out_elems = out_rows * p.ldo; op.out_bf16 = (ek == EK_GATE || ek == EK_BIASBF16 || ek == EK_DWGATE) ? 1 : 0;
     Chain* chp = c->ch;
-    op.run = [c, chp, p, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
-                        if (film && p.film == nullptr) {          // denoiser FiLM rows live in the (re-allocatable) table
-                            GemmP q = p;
+    auto gp = std::make_shared<GemmP>(p);
+    op.gemm = gp;
+    op.skinny_affine = p.xcd_tile_affine && t128 != 0 && t128 != 1 && t128 != 4;     // modes 0/1/4 are the tall kernel
+    op.run = [c, chp, gp, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
+                        if (film && gp->film == nullptr) {        // denoiser FiLM rows live in the (re-allocatable) table
+                            GemmP q = *gp;
                             q.film = c->film_from_cur ? chp->film_cur : c->film_table;
                             q.film_face_stride = c->film_face_stride;
                             q.film_step_stride = 0;
                             q.step_ptr = nullptr;
                             return dispatch_gemm(q, lk, ek, t128, s);
                         }
-                        return dispatch_gemm(p, lk, ek, t128, s);
+                        return dispatch_gemm(*gp, lk, ek, t128, s);
                     };
     prog.push_back(op);
 }
@@ -607,6 +613,28 @@ void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Hc
     add_gemm(c, prog, name, p, LK_CONV_BF16, EK_BIASF32);
 }
 
+// Each skinny GEMM can touch the weight tiles of the next weight-dominant skinny GEMM of the program (wrapping
+// around: the program is replayed every diffusion step), see prefetch_issue in hd_gemm.hpp.  Measured (r01):
+// consumers get 0.5-1 us faster (L2-latency instead of HBM-latency ingest) but the producers, themselves ingest
+// bound with no idle memory phase, slow down by more (1592 -> 1633 us/step), so it is OFF unless HD_PREFETCH is set.
+void link_prefetch(std::vector<Op>& prog, bool wrap) {
+    static const bool off = getenv("HD_PREFETCH") == nullptr;
+    static const size_t min_bytes = getenv("HD_PF_MIN") ? (size_t)atol(getenv("HD_PF_MIN")) : (size_t)1 << 20;
+    const int n = (int)prog.size();
+    for (int i = 0; i < n; ++i) {
+        if (!prog[i].gemm) continue;
+        prog[i].gemm->pf_base = nullptr;
+        if (off) continue;
+        // the very next launch only: data touched earlier would be evicted by the launches in between
+        const int j = (i + 1 < n) ? i + 1 : (wrap ? 0 : -1);
+        if (j < 0 || !prog[j].gemm || !prog[j].skinny_affine) continue;
+        const GemmP& nx = *prog[j].gemm;
+        const size_t tile_bytes = (size_t)nx.Kp * 32 * 2;
+        if ((size_t)nx.nt_total * tile_bytes < min_bytes) continue;
+        prog[i].gemm->pf_base = nx.W; prog[i].gemm->pf_tile_u4 = (unsigned)(tile_bytes / 16); prog[i].gemm->pf_ntiles = nx.nt_total;
+    }
+}
+
 int run_ops(hd_ctx* c, std::vector<Op>& prog, hipStream_t s, int limit = -1) {
     int n = 0;
     for (auto& op : prog) {
@@ -766,6 +794,7 @@ int build_denoiser_program(hd_ctx* c) {
                         }});
         prog.back().out = eps; prog.back().out_elems = (size_t)B * 4 * L * L;
     }
+    link_prefetch(prog, true);
     return HD_OK;
 }
 
