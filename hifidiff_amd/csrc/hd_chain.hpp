@@ -33,10 +33,14 @@ struct ChainP {
     const float *gate_c, *gate_s, *add_src;
 };
 
-template <int C>
+// MT: 32-row MFMA tiles per wave (BM = 32*MT rows per workgroup).  A workgroup re-reads all 5*C*C weights of the
+// block; MT = 2 halves that traffic at level 0 but leaves a single 4-wave workgroup per CU, whose barrier-separated
+// phases then have nothing to overlap with (measured slower: 21.4 vs 16.8 us), so MT = 1 is what runs.
+template <int C, int MT_ = 1>
 struct ChainCfg {
     static constexpr int NT = C / 32;                    // 32-column tiles of a C-wide output
-    static constexpr int WAVES = NT, THREADS = 64 * WAVES, BM = 32;   // one column tile per wave (4 waves at C=128, 8 at C=256)
+    static constexpr int MT = MT_;
+    static constexpr int WAVES = NT, THREADS = 64 * WAVES, BM = 32 * MT;   // one column tile per wave (4 waves at C=128, 8 at C=256)
     static constexpr int TPW = 1;
     static constexpr int KS = C / 16;                    // k-steps of a K = C GEMM
     static constexpr int AROW = C * 2 + 16;              // bytes per bf16 A-tile row (padded)
@@ -58,23 +62,28 @@ __device__ __forceinline__ void chain_load_b(const uint4* W, int tile, int lane,
 #pragma unroll
     for (int ks = 0; ks < ChainCfg<C>::KS; ++ks) b[ks] = Wl[ks * 64];
 }
-template <int C>
-__device__ __forceinline__ void chain_mma(const char* sA, const uint4* b, int lane, f32x16_t& acc) {
+template <int C, int MT>
+__device__ __forceinline__ void chain_mma(const char* sA, const uint4* b, int lane, f32x16_t (&acc)[MT]) {
     const char* ap = sA + (lane & 31) * ChainCfg<C>::AROW + (lane >> 5) * 16;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < ChainCfg<C>::KS; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + ks * 32), __builtin_bit_cast(bf16x8_t, b[ks]), acc, 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + mt * 32 * ChainCfg<C>::AROW + ks * 32),
+                                                              __builtin_bit_cast(bf16x8_t, b[ks]), acc[mt], 0, 0, 0);
 }
 
-template <int C>
-__global__ __launch_bounds__(ChainCfg<C>::THREADS) void naf_chain_kernel(const ChainP p) {
-    typedef ChainCfg<C> K;
+template <int C, int MT>
+__global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(const ChainP p) {
+    typedef ChainCfg<C, MT> K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * K::BM;
-    const int face = row0 / p.hw;                                  // 32 rows never straddle faces (hw % 32 == 0)
+    const int face = row0 / p.hw;                                  // BM rows never straddle faces (hw % BM == 0: host)
     float* s_vec = reinterpret_cast<float*>(smem + K::S_OFF);
     float* gb = reinterpret_cast<float*>(smem + K::GB_OFF);
     float* yt = reinterpret_cast<float*>(smem + K::Y_OFF);
@@ -113,12 +122,14 @@ __global__ __launch_bounds__(ChainCfg<C>::THREADS) void naf_chain_kernel(const C
     }
     chain_load_b<C>(p.W3, tile, lane, bw);                         // conv3 weights fly during the staging below
     // residual x for this wave's tile (needed by the conv3 epilogue): request it now as well
-    float xr[16];
+    float xr[MT][16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        xr[i] = (full || row0 + rl < p.M) ? p.X[(size_t)(row0 + rl) * C + col] : 0.f;
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            xr[mt][i] = (full || row0 + rl < p.M) ? p.X[(size_t)(row0 + rl) * C + col] : 0.f;
+        }
     __syncthreads();
 
     // ---- A1 = bf16(G * s): 32 rows x C, whole 128-byte lines ----
@@ -142,16 +153,18 @@ __global__ __launch_bounds__(ChainCfg<C>::THREADS) void naf_chain_kernel(const C
 
     // ---- conv3 -> y = x + beta * (acc + b3) into LDS ----
     {
-        f32x16_t acc;
-        chain_mma<C>(smem + K::A1_OFF, bw, lane, acc);
+        f32x16_t acc[MT];
+        chain_mma<C, MT>(smem + K::A1_OFF, bw, lane, acc);
         chain_load_b<C>(p.W4, tile, lane, bw);                     // conv4 weights (both gate halves) for later
         chain_load_b<C>(p.W4, tile + K::NT, lane, bw2);
         const float bb = p.b3[col], be = p.beta[col];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            yt[rl * K::YROW + col] = xr[i] + (acc[i] + bb) * be;
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                yt[rl * K::YROW + col] = xr[mt][i] + (acc[mt][i] + bb) * be;
+            }
     }
     __syncthreads();
 
@@ -185,77 +198,84 @@ __global__ __launch_bounds__(ChainCfg<C>::THREADS) void naf_chain_kernel(const C
 
     // ---- conv4 (tile j and tile j + C/32) -> SimpleGate -> A3 (reuses the A1 region) ----
     {
-        f32x16_t acc1, acc2;
-        chain_mma<C>(smem + K::A2_OFF, bw, lane, acc1);
-        chain_mma<C>(smem + K::A2_OFF, bw2, lane, acc2);
+        f32x16_t acc1[MT], acc2[MT];
+        chain_mma<C, MT>(smem + K::A2_OFF, bw, lane, acc1);
+        chain_mma<C, MT>(smem + K::A2_OFF, bw2, lane, acc2);
         chain_load_b<C>(p.W5, tile, lane, bw);                     // conv5 weights
         char* sA = smem + K::A1_OFF;
         const float b1 = p.b4[col], b2 = p.b4[col + C];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            *reinterpret_cast<unsigned short*>(sA + rl * K::AROW + col * 2) = f32_to_bf16_bits((acc1[i] + b1) * (acc2[i] + b2));
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                *reinterpret_cast<unsigned short*>(sA + rl * K::AROW + col * 2) = f32_to_bf16_bits((acc1[mt][i] + b1) * (acc2[mt][i] + b2));
+            }
     }
     __syncthreads();
 
     // ---- conv5 -> x' = y + gamma * (acc + b5): fp32, bf16 copy, LayerNorm partials, optional HCA-gated copy ----
     {
-        f32x16_t acc;
-        chain_mma<C>(smem + K::A1_OFF, bw, lane, acc);
+        f32x16_t accs[MT];
+        chain_mma<C, MT>(smem + K::A1_OFF, bw, lane, accs);
         const float bb = p.b5[col], ga = p.gamma[col];
-        float v[16], gat[16];
-        if (p.outg16) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                const bool ok = full || row < p.M;
-                const float a = (ok && p.add_src) ? p.add_src[(size_t)row * C + col] : 0.f;
-                gat[i] = ok ? 1.0f + p.gate_c[(size_t)face * C + col] + p.gate_s[row] : 0.f;   // gates are per launch (chain-local faces)
-                v[i] = a;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            const int row = row0 + rl;
-            const float add = p.outg16 ? v[i] : 0.f;
-            v[i] = yt[rl * K::YROW + col] + (acc[i] + bb) * ga;
-            if (full || row < p.M) {
-                p.Xout[(size_t)row * C + col] = v[i];
-                if (p.Xout16) p.Xout16[(size_t)row * C + col] = f32_to_bf16_bits(v[i]);
-                if (p.outg16) p.outg16[(size_t)row * C + col] = f32_to_bf16_bits((v[i] + add) * gat[i]);
-            } else {
-                v[i] = 0.f;
-            }
-        }
-        if (p.stats_out) {
-            float2 ms[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ms[i] = halfwave_mean_m2(v[i]);
-            if ((lane & 31) == kStatLane) {
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x16_t& acc = accs[mt];
+            const int rb = row0 + mt * 32;
+            float v[16], gat[16];
+            if (p.outg16) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                    if (full || row < p.M) p.stats_out[(size_t)row * (C / 32) + tile] = ms[i];
+                    const int row = rb + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    const bool ok = full || row < p.M;
+                    const float a = (ok && p.add_src) ? p.add_src[(size_t)row * C + col] : 0.f;
+                    gat[i] = ok ? 1.0f + p.gate_c[(size_t)face * C + col] + p.gate_s[row] : 0.f;   // gates are per launch (chain-local faces)
+                    v[i] = a;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int row = row0 + rl;
+                const float add = p.outg16 ? v[i] : 0.f;
+                v[i] = yt[rl * K::YROW + col] + (acc[i] + bb) * ga;
+                if (full || row < p.M) {
+                    p.Xout[(size_t)row * C + col] = v[i];
+                    if (p.Xout16) p.Xout16[(size_t)row * C + col] = f32_to_bf16_bits(v[i]);
+                    if (p.outg16) p.outg16[(size_t)row * C + col] = f32_to_bf16_bits((v[i] + add) * gat[i]);
+                } else {
+                    v[i] = 0.f;
+                }
+            }
+            if (p.stats_out) {
+                float2 ms[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ms[i] = halfwave_mean_m2(v[i]);
+                if ((lane & 31) == kStatLane) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = rb + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                        if (full || row < p.M) p.stats_out[(size_t)row * (C / 32) + tile] = ms[i];
+                    }
                 }
             }
         }
     }
 }
 
-template <int C>
+template <int C, int MT>
 inline hipError_t launch_chain(const ChainP& p, hipStream_t s) {
-    typedef ChainCfg<C> K;
+    typedef ChainCfg<C, MT> K;
     if (K::SMEM > 65536) {
         static bool granted = false;
         if (!granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&naf_chain_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&naf_chain_kernel<C, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
             if (e != hipSuccess) return e;
             granted = true;
         }
     }
-    hipLaunchKernelGGL((naf_chain_kernel<C>), dim3((p.M + K::BM - 1) / K::BM), dim3(K::THREADS), K::SMEM, s, p);
+    hipLaunchKernelGGL((naf_chain_kernel<C, MT>), dim3((p.M + K::BM - 1) / K::BM), dim3(K::THREADS), K::SMEM, s, p);
     return hipGetLastError();
 }
 

@@ -504,15 +504,19 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         if (gate) { q.outg16 = lv.Xg; q.gate_c = gate->gate_c; q.gate_s = gate->gate_s; q.add_src = gate->add; q.stats_out = nullptr; q.Xout16 = nullptr; }
         Chain* chp = c->ch;
         const bool big = (C == 256);
+        // 64-row workgroups at level 0 halve the weight re-reads but leave one 4-wave workgroup per CU with nothing to
+        // overlap its barrier-separated phases with: measured 21.4 us against 16.8 us for 32-row tiles (two per CU) -> opt-in
+        static const int mt128 = getenv("HD_CHAIN_MT") ? atoi(getenv("HD_CHAIN_MT")) : 1;
+        const bool two = !big && mt128 == 2 && HW % 64 == 0 && M % 64 == 0;
         Op op;
         op.name = bw.name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)M * C; op.out_bf16 = 0;
-        op.run = [c, chp, q, big](hipStream_t s) mutable -> hipError_t {
+        op.run = [c, chp, q, big, two](hipStream_t s) mutable -> hipError_t {
             ChainP r = q;
             if (r.film == nullptr) {                      // denoiser: FiLM rows live in the (re-allocatable) table
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table; r.film_face_stride = c->film_face_stride; r.film_step_stride = 0;
                 r.step_ptr = nullptr;
             }
-            return big ? launch_chain<256>(r, s) : launch_chain<128>(r, s);
+            return big ? launch_chain<256, 1>(r, s) : two ? launch_chain<128, 2>(r, s) : launch_chain<128, 1>(r, s);
         };
         prog.push_back(op);
         *x_np = C / 32; *x_cnt = 32;
