@@ -254,44 +254,72 @@ __global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restric
 // (conditional_naf.py:116-119 / naf.py:109-112).  T1 is the fp32 conv1 output [rows][2C].
 // grid (C/32, faces); a workgroup owns one face x 32 gate channels, so the pooled mean is complete
 // without atomics.
+// Unfused form (faces too large for the fused conv1 epilogue: side > 16).  grid (C/32, faces, bands): a workgroup
+// owns 32 gate channels x a band of 8 image rows of one face; each of its 8 row workers slides a 3x3 window along
+// its row (6 new values per pixel per gate half instead of 18).  Band sums go to pool_part[face][band][C]; the
+// mean over the face is finished by dwconv_pool_finish_kernel in band order (no atomics: reproducible).
 __global__ __launch_bounds__(256) void dwconv_gate_pool_kernel(const float* __restrict__ T1, const float* __restrict__ w2,
                                                                 const float* __restrict__ b2,
-                                                                unsigned short* __restrict__ G, float* __restrict__ pooled,
+                                                                unsigned short* __restrict__ G, float* __restrict__ pool_part,
                                                                 int H, int W, int C) {
     __shared__ float red[8][32];
     const int j = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int pg = threadIdx.x >> 5;
-    const int face = blockIdx.y;
+    const int rw = threadIdx.x >> 5;
+    const int face = blockIdx.y, band = blockIdx.z, nbands = gridDim.z;
     const int HW = H * W, C2 = 2 * C;
     float wa[9], wb[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) { wa[t] = w2[(size_t)j * 9 + t]; wb[t] = w2[(size_t)(j + C) * 9 + t]; }
     const float ba = b2[j], bb = b2[j + C];
     const float* base = T1 + (size_t)face * HW * C2;
+    const int y = band * 8 + rw;
     float sum = 0.f;
-    for (int p = pg; p < HW; p += 8) {
-        const int y = p / W, x = p - y * W;
-        float u1 = ba, u2 = bb;
+    if (y < H) {
+        // column x of the three rows y-1, y, y+1 for both gate halves (zeros outside the image)
+        auto load_col = [&](int x, float (&a)[3], float (&b)[3]) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-            const float* q = base + (size_t)(yy * W + xx) * C2;
-            u1 += wa[t] * q[j];
-            u2 += wb[t] * q[j + C];
+            for (int r = 0; r < 3; ++r) {
+                const int yy = y + r - 1;
+                const bool in = yy >= 0 && yy < H && x >= 0 && x < W;
+                const float* q = base + (size_t)(in ? yy * W + x : 0) * C2;
+                const float va = q[j], vb = q[j + C];
+                a[r] = in ? va : 0.f; b[r] = in ? vb : 0.f;
+            }
+        };
+        float la[3], lb[3], ca[3], cb[3], ra[3], rb[3];
+        load_col(-1, la, lb);
+        load_col(0, ca, cb);
+        for (int x = 0; x < W; ++x) {
+            load_col(x + 1, ra, rb);
+            float u1 = ba, u2 = bb;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                u1 += wa[r * 3] * la[r] + wa[r * 3 + 1] * ca[r] + wa[r * 3 + 2] * ra[r];
+                u2 += wb[r * 3] * lb[r] + wb[r * 3 + 1] * cb[r] + wb[r * 3 + 2] * rb[r];
+            }
+            const float g = u1 * u2;
+            G[((size_t)face * HW + y * W + x) * C + j] = f32_to_bf16_bits(g);
+            sum += g;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { la[r] = ca[r]; lb[r] = cb[r]; ca[r] = ra[r]; cb[r] = rb[r]; }
         }
-        const float g = u1 * u2;
-        G[((size_t)face * HW + p) * C + j] = f32_to_bf16_bits(g);
-        sum += g;
     }
-    red[pg][threadIdx.x & 31] = sum;
+    red[rw][threadIdx.x & 31] = sum;
     __syncthreads();
-    if (pg == 0) {
+    if (rw == 0) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += red[i][threadIdx.x];
-        pooled[(size_t)face * C + j] = s / (float)HW;
+        pool_part[((size_t)face * nbands + band) * C + j] = s;
     }
+}
+__global__ void dwconv_pool_finish_kernel(const float* __restrict__ pool_part, float* __restrict__ pooled, int faces, int nbands, int C, float inv_hw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= faces * C) return;
+    const int face = i / C, j = i - face * C;
+    float s = 0.f;
+    for (int b = 0; b < nbands; ++b) s += pool_part[((size_t)face * nbands + b) * C + j];
+    pooled[i] = s * inv_hw;
 }
 
 // -------------------------------------------------------------------------------------- FiLM path

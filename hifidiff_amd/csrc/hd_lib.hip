@@ -484,11 +484,19 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
             const float *T1 = lv.T1, *w = bw.dw_w, *b = bw.dw_b;
             unsigned short* G = lv.G; float* pooled = lv.pooled;
             const int H = lv.H, faces = M / HW;
+            float* part = lv.T1 + (size_t)2 * M * C;        // band sums live behind T1 (alloc_chain reserves the room)
+            const int nbands = (H + 7) / 8;
             prog.push_back({bw.name + ".conv2_gate_pool", [=](hipStream_t s) -> hipError_t {
-                                hipLaunchKernelGGL(dwconv_gate_pool_kernel, dim3(C / 32, faces), dim3(256), 0, s, T1, w, b, G, pooled, H, H, C);
+                                hipLaunchKernelGGL(dwconv_gate_pool_kernel, dim3(C / 32, faces, nbands), dim3(256), 0, s, T1, w, b, G, part, H, H, C);
                                 return hipGetLastError();
                             }});
             prog.back().out = G; prog.back().out_elems = (size_t)M * C; prog.back().out_bf16 = 1;
+            prog.push_back({bw.name + ".pool_finish", [=](hipStream_t s) -> hipError_t {
+                                hipLaunchKernelGGL(dwconv_pool_finish_kernel, dim3((faces * C + 255) / 256), dim3(256), 0, s, part, pooled, faces, nbands, C,
+                                                   1.0f / (float)(H * H));
+                                return hipGetLastError();
+                            }});
+            prog.back().out = pooled; prog.back().out_elems = (size_t)faces * C;
         }
     }
     static const bool no_chain = getenv("HD_NO_CHAIN") != nullptr;
@@ -659,7 +667,7 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
         Level& v = ch.lv[l];
         v.C = WIDTH << l; v.H = L >> l; v.M = B * v.H * v.H;
         const size_t mc = (size_t)v.M * v.C;
-        rc |= dev_alloc(c, &v.X, mc); rc |= dev_alloc(c, &v.Y, mc); rc |= dev_alloc(c, &v.T1, 2 * mc);
+        rc |= dev_alloc(c, &v.X, mc); rc |= dev_alloc(c, &v.Y, mc); rc |= dev_alloc(c, &v.T1, 2 * mc + (size_t)B * ((v.H + 7) / 8) * v.C);   // + per-band pool sums of the unfused depthwise path
         rc |= dev_alloc(c, &v.G, mc); rc |= dev_alloc(c, &v.pooled, (size_t)B * v.C); rc |= dev_alloc(c, &v.S, (size_t)B * v.C);
         rc |= dev_alloc(c, &v.sx, (size_t)v.M * (v.C / 32)); rc |= dev_alloc(c, &v.sy, (size_t)v.M * (v.C / 32));
         rc |= dev_alloc(c, &v.Xb, mc); rc |= dev_alloc(c, &v.Yb, mc); rc |= dev_alloc(c, &v.Xg, mc);
