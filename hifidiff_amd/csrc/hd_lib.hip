@@ -631,12 +631,14 @@ void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Hc
 // bound with no idle memory phase, slow down by more (1592 -> 1633 us/step), so it is OFF unless HD_PREFETCH is set.
 void link_prefetch(std::vector<Op>& prog, bool wrap) {
     static const bool off = getenv("HD_PREFETCH") == nullptr;
+    static const std::string only = getenv("HD_PREFETCH") ? getenv("HD_PREFETCH") : "";   // "1": every GEMM; else producer-name suffix
     static const size_t min_bytes = getenv("HD_PF_MIN") ? (size_t)atol(getenv("HD_PF_MIN")) : (size_t)1 << 20;
     const int n = (int)prog.size();
     for (int i = 0; i < n; ++i) {
         if (!prog[i].gemm) continue;
         prog[i].gemm->pf_base = nullptr;
         if (off) continue;
+        if (only != "1" && (prog[i].name.size() < only.size() || prog[i].name.compare(prog[i].name.size() - only.size(), only.size(), only) != 0)) continue;
         // the very next launch only: data touched earlier would be evicted by the launches in between
         const int j = (i + 1 < n) ? i + 1 : (wrap ? 0 : -1);
         if (j < 0 || !prog[j].gemm || !prog[j].skinny_affine) continue;
