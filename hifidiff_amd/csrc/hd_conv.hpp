@@ -1,0 +1,180 @@
+// hd_conv.hpp — 3x3 (pad 1) convolution C -> C on small faces as an implicit GEMM whose A operand never leaves
+// LDS: the HCA conv `fused_mlp` of models/fpg/hca.py:21-23,29 (BatchNorm folded, ReLU).
+//
+// The gather form of this conv (hd_gemm.hpp, LdConv) re-reads every input pixel nine times through L1 and, with
+// waves stacked along M, every weight fragment once per wave: at level 0 that is 1.15 MB of loads per workgroup
+// for 138 KB of distinct bytes, and the kernel runs at the per-CU ingest limit (25 us).  Here a workgroup stages
+// the whole faces that contain its BM rows once (bf16, NP pixels + one zero row), each wave builds its MFMA A
+// fragments from LDS with the tap shift applied to the row address, and the only global stream in the K loop is
+// the packed weights (k = tap*C + c order, as packed for LdConv).
+//
+//   grid (M / BM, C / 32); 8 waves = RG row groups (MT 32-row tiles each) x KS slices of the input channels (every
+//   wave walks all nine taps over its C/KS channels, so the tap -- and with it the LDS row shift -- is a
+//   compile-time constant of the unrolled loop); KS > 1: partial tiles are summed through LDS in slice order.
+#pragma once
+#include "hd_gemm.hpp"
+
+namespace hd {
+
+struct ConvP {
+    int M;                            // rows (pixels) of the level
+    const unsigned short* X;          // [M][C] bf16 input (pre-gated f_d)
+    const uint4* W;                   // packed [C/32][9*C/16][64] uint4
+    const float* bias;                // [C] (BN folded)
+    float* out;                       // [M][C] fp32, ReLU applied
+    unsigned short* out16;            // bf16 copy or NULL
+};
+
+template <int C_, int S_, int BM_, int MT_, int KS_, int DEPTH_ = 8>
+struct ConvCfg {
+    static constexpr int C = C_, S = S_, HW = S_ * S_, BM = BM_, MT = MT_, KS = KS_;
+    static constexpr int RG = BM / (32 * MT);                    // row groups
+    static constexpr int WAVES = RG * KS, THREADS = 64 * WAVES;
+    static constexpr int NP = BM > HW ? BM : HW;                 // staged pixels: whole faces covering the BM rows
+    static constexpr int ROWB = C * 2 + 16;                      // bytes per staged pixel (padded against bank conflicts)
+    static constexpr int KSTEPS = 9 * C / 16;                    // k-steps of the whole K = 9*C
+    static constexpr int SPT = C / 16, CPW = SPT / KS;           // k-steps per tap: all channels / this wave's slice
+    static constexpr int NSTEP = 9 * CPW;                        // k-steps per wave
+    static constexpr int XIN = (NP + 1) * ROWB;                  // + one zero row for taps outside the face
+    static constexpr int RED = KS > 1 ? KS * BM * 32 * 4 : 0;    // partial tiles (aliases the staging area)
+    static constexpr int SMEM = XIN > RED ? XIN : RED;
+    static constexpr int DEPTH = DEPTH_;                         // weight fragments (1 KiB each) in flight per wave
+    static_assert(WAVES == 8 || WAVES == 4, "4 or 8 waves");
+    static_assert(NSTEP >= DEPTH, "prefetch ring longer than the loop");
+    static_assert(SPT % KS == 0 && BM % (32 * MT) == 0, "shape");
+    static_assert((HW >= BM && HW % BM == 0) || (BM % HW == 0), "row tiles are whole faces or a face is whole row tiles");
+};
+
+template <class K>
+__global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int C = K::C, S = K::S, HW = K::HW, MT = K::MT, KS = K::KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = wave / KS, ksl = wave - rg * KS;
+    // XCD-aware block -> (row group, weight tile) map (as in gemm_skinny_kernel): the row groups that stream the
+    // same weight tile get linear ids that are equal mod 8, i.e. run on one XCD and share the tile through its L2
+    int bx = blockIdx.x, tile = blockIdx.y;
+    if (K::C >= 1024 && (gridDim.y & 7) == 0 && gridDim.x > 1) {      // only where the weights dwarf the activations (measured)
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, j = lin >> 3;
+        bx = j % (int)gridDim.x;
+        tile = (j / (int)gridDim.x) * 8 + (lin & 7);
+    }
+    const int row0 = bx * K::BM;
+    const int pix0 = (row0 / K::NP) * K::NP;                       // first staged pixel (face aligned)
+    // weights first: independent of everything else.  Step n = tap * CPW + j reads k-step tap * SPT + ksl * CPW + j.
+    uint4 bq[K::DEPTH];
+    const uint4* Wl = p.W + ((size_t)tile * K::KSTEPS + ksl * K::CPW) * 64 + lane;
+#define HD_CONV_B(n) Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64]
+#pragma unroll
+    for (int d = 0; d < K::DEPTH; ++d) bq[d] = HD_CONV_B(d);
+
+    // ---- stage the faces (16-byte pieces, whole lines) and the zero row ----
+    {
+        constexpr int PPR = C / 8;                                 // pieces per pixel
+        const uint4* src = reinterpret_cast<const uint4*>(p.X + (size_t)pix0 * C);
+        for (int i = tid; i < K::NP * PPR; i += K::THREADS) {
+            const int px = i / PPR, q = i - px * PPR;
+            const uint4 v = (pix0 + px < p.M) ? src[i] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(smem + px * K::ROWB + q * 16) = v;
+        }
+        for (int i = tid; i < K::ROWB / 16; i += K::THREADS) *reinterpret_cast<uint4*>(smem + K::NP * K::ROWB + i * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // ---- per lane: LDS byte offset of the source pixel of (row tile mt, tap), zero row when outside the face ----
+    int src_off[MT][9];
+    {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pl = (row0 - pix0) + (rg * MT + mt) * 32 + r;                 // staged-pixel index of this row
+            const int f = pl / HW, rem = pl - f * HW, y = rem / S, x = rem - y * S;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
+                src_off[mt][t] = (in ? (f * HW + yy * S + xx) : K::NP) * K::ROWB + h * 16;
+            }
+        }
+    }
+    f32x16_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    __syncthreads();
+
+    // ---- K loop, fully unrolled: 9 taps x CPW k-steps of this wave's channel slice ----
+    const int cbase = ksl * K::CPW * 32;                           // byte offset of the slice inside a staged pixel
+#pragma unroll
+    for (int n = 0; n < K::NSTEP; ++n) {
+        const int tap = n / K::CPW, j = n % K::CPW;                // compile-time after unrolling
+        bf16x8_t a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8_t*>(smem + src_off[mt][tap] + cbase + j * 32);
+        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, bq[n % K::DEPTH]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
+        if (n + K::DEPTH < K::NSTEP) bq[n % K::DEPTH] = HD_CONV_B(n + K::DEPTH);
+    }
+#undef HD_CONV_B
+
+    // ---- K-slice partials through LDS (slice order), then bias + ReLU + stores ----
+    const int col = tile * 32 + (lane & 31);
+    const float bias = p.bias[col];
+    if constexpr (KS > 1) {
+        __syncthreads();                                           // staged faces are dead
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (rg * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                red[(ksl * K::BM + r) * 32 + (lane & 31)] = acc[mt][i];
+            }
+        __syncthreads();
+        for (int e = tid; e < K::BM * 32; e += K::THREADS) {
+            float v = bias;                                        // e & 31 == lane & 31 (THREADS % 32 == 0): same column
+#pragma unroll
+            for (int s = 0; s < KS; ++s) v += red[s * K::BM * 32 + e];
+            v = fmaxf(v, 0.f);
+            const int row = row0 + (e >> 5);
+            if (row < p.M) {
+                p.out[(size_t)row * C + col] = v;
+                if (p.out16) p.out16[(size_t)row * C + col] = f32_to_bf16_bits(v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + (rg * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const float v = fmaxf(acc[mt][i] + bias, 0.f);
+                if (row < p.M) {
+                    p.out[(size_t)row * C + col] = v;
+                    if (p.out16) p.out16[(size_t)row * C + col] = f32_to_bf16_bits(v);
+                }
+            }
+    }
+}
+
+template <class K>
+inline hipError_t launch_hca_conv(const ConvP& p, hipStream_t s) {
+    if (K::SMEM > 65536) {
+        static bool granted = false;
+        if (!granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hca_conv_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+            if (e != hipSuccess) return e;
+            granted = true;
+        }
+    }
+    hipLaunchKernelGGL((hca_conv_kernel<K>), dim3((p.M + K::BM - 1) / K::BM, K::C / 32), dim3(K::THREADS), K::SMEM, s, p);
+    return hipGetLastError();
+}
+
+// Shapes of the refiner at latent 16: level l has C = 128 << l channels and faces of side 16 >> l.
+typedef ConvCfg<128, 16, 256, 2, 2> ConvL0;    // one face per workgroup: 4 row groups x 2 K-halves
+typedef ConvCfg<256, 8, 128, 2, 4> ConvL1;     // two faces: 2 row groups x 4 K-quarters
+typedef ConvCfg<512, 4, 64, 2, 8> ConvL2;      // four faces: 1 row group x 8 K-slices
+typedef ConvCfg<1024, 2, 32, 1, 8, 16> ConvL3; // eight faces; 590 KB of weights per workgroup: deeper ring
+
+}  // namespace hd

@@ -15,6 +15,7 @@
 
 #include "../../include/hifidiff_hip.h"
 #include "hd_chain.hpp"
+#include "hd_conv.hpp"
 #include "hd_gemm.hpp"
 #include "hd_kernels.hpp"
 
@@ -617,6 +618,27 @@ void add_up(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Pac
 // plain bf16 implicit GEMM; BN folded, ReLU; fp32 output (+ bf16 copy for the up-conv that follows).
 void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const HcaW& hw, const unsigned short* in, float* out,
              unsigned short* out16, int M, int H) {
+    static const bool no_lds = getenv("HD_NO_CONVLDS") != nullptr;
+    if (!hw.centre_only && !no_lds && c->L == 16) {
+        // faces small enough to sit in LDS: the A operand is built from the staged faces (hd_conv.hpp)
+        ConvP q{};
+        q.M = M; q.X = in; q.W = hw.fused.w; q.bias = hw.fused.bias; q.out = out; q.out16 = out16;
+        const int C = hw.C;
+        if ((C == 128 && H == 16) || (C == 256 && H == 8) || (C == 512 && H == 4) || (C == 1024 && H == 2)) {
+            Op op;
+            op.name = name; op.out = out; op.out_elems = (size_t)M * C;
+            op.run = [q, C](hipStream_t s) -> hipError_t {
+                switch (C) {
+                    case 128: return launch_hca_conv<ConvL0>(q, s);
+                    case 256: return launch_hca_conv<ConvL1>(q, s);
+                    case 512: return launch_hca_conv<ConvL2>(q, s);
+                    default: return launch_hca_conv<ConvL3>(q, s);
+                }
+            };
+            prog.push_back(op);
+            return;
+        }
+    }
     GemmP p = base_gemm(hw.fused, M);
     p.A = in; p.lda = hw.C; p.Hin = H; p.Win = H; p.Cin = hw.C; p.Hout = H; p.Wout = H; p.stride = 1;
     if (hw.centre_only) { p.KH = 1; p.KW = 1; p.pad = 0; p.ntaps = 1; }
