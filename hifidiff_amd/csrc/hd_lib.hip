@@ -409,8 +409,11 @@ int choose_mode(const GemmP& p, bool pair) {
         if (((p.M + 255) / 256) * nb32 >= 256) return 6;
         if (((p.M + 127) / 128) * nb32 >= 192) return 5;
     }
-    if (((p.M + 127) / 128) * nb64 >= 256) return 0;
-    if (((p.M + 63) / 64) * nb64 >= 256) return 1;
+    static const int tall_maxk = getenv("HD_TALL_MAXK") ? atoi(getenv("HD_TALL_MAXK")) : 128;   // the tall kernel prefetches one chunk ahead only: with more than two K chunks the skinny kernel (whole K slice in flight) wins even at large M (measured)
+    if (p.Kp <= tall_maxk) {
+        if (((p.M + 127) / 128) * nb64 >= 256) return 0;
+        if (((p.M + 63) / 64) * nb64 >= 256) return 1;
+    }
     if (((p.M + 63) / 64) * nb32 >= 192) return 2;
     return 3;
 }
