@@ -176,5 +176,10 @@ typedef ConvCfg<128, 16, 256, 2, 2> ConvL0;    // one face per workgroup: 4 row 
 typedef ConvCfg<256, 8, 128, 2, 4> ConvL1;     // two faces: 2 row groups x 4 K-quarters
 typedef ConvCfg<512, 4, 64, 2, 8> ConvL2;      // four faces: 1 row group x 8 K-slices
 typedef ConvCfg<1024, 2, 32, 1, 8, 16> ConvL3; // eight faces; 590 KB of weights per workgroup: deeper ring
+// latent 32: faces of side 32 >> l (level 0's 32x32 faces do not fit LDS and keep the gather form)
+typedef ConvCfg<256, 16, 256, 2, 2> ConvL1x32;
+typedef ConvCfg<512, 8, 64, 2, 8> ConvL2x32;
+typedef ConvCfg<1024, 4, 32, 1, 8, 16> ConvL3x32;
+typedef ConvCfg<2048, 2, 32, 1, 8, 16> ConvL4x32;
 
 }  // namespace hd

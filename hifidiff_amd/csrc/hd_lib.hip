@@ -622,20 +622,28 @@ void add_up(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Pac
 void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const HcaW& hw, const unsigned short* in, float* out,
              unsigned short* out16, int M, int H) {
     static const bool no_lds = getenv("HD_NO_CONVLDS") != nullptr;
-    if (!hw.centre_only && !no_lds && c->L == 16) {
+    if (!hw.centre_only && !no_lds) {
         // faces small enough to sit in LDS: the A operand is built from the staged faces (hd_conv.hpp)
         ConvP q{};
         q.M = M; q.X = in; q.W = hw.fused.w; q.bias = hw.fused.bias; q.out = out; q.out16 = out16;
         const int C = hw.C;
-        if ((C == 128 && H == 16) || (C == 256 && H == 8) || (C == 512 && H == 4) || (C == 1024 && H == 2)) {
+        int which = -1;
+        if (C == 128 && H == 16) which = 0; else if (C == 256 && H == 8) which = 1; else if (C == 512 && H == 4) which = 2;
+        else if (C == 1024 && H == 2) which = 3; else if (C == 256 && H == 16) which = 4; else if (C == 512 && H == 8) which = 5;
+        else if (C == 1024 && H == 4) which = 6; else if (C == 2048 && H == 2) which = 7;
+        if (which >= 0) {
             Op op;
             op.name = name; op.out = out; op.out_elems = (size_t)M * C;
-            op.run = [q, C](hipStream_t s) -> hipError_t {
-                switch (C) {
-                    case 128: return launch_hca_conv<ConvL0>(q, s);
-                    case 256: return launch_hca_conv<ConvL1>(q, s);
-                    case 512: return launch_hca_conv<ConvL2>(q, s);
-                    default: return launch_hca_conv<ConvL3>(q, s);
+            op.run = [q, which](hipStream_t s) -> hipError_t {
+                switch (which) {
+                    case 0: return launch_hca_conv<ConvL0>(q, s);
+                    case 1: return launch_hca_conv<ConvL1>(q, s);
+                    case 2: return launch_hca_conv<ConvL2>(q, s);
+                    case 3: return launch_hca_conv<ConvL3>(q, s);
+                    case 4: return launch_hca_conv<ConvL1x32>(q, s);
+                    case 5: return launch_hca_conv<ConvL2x32>(q, s);
+                    case 6: return launch_hca_conv<ConvL3x32>(q, s);
+                    default: return launch_hca_conv<ConvL4x32>(q, s);
                 }
             };
             prog.push_back(op);
