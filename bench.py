@@ -184,7 +184,7 @@ def main():
                          "avg_launch_ms": round(step_ms_avg.value, 4),
                          "mfma_frac": round(SURVEY_FLOPS_PER_FACE_STEP.get(L, fl.value) * B / step_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if step_s > 0 else None},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:              # the CPU leg is reported at N=1 only
             sdt, sb, sn, _ = cpu_baseline(P, a.latent, a.kind)
             res["cpu_baseline"] = {
                 "value": round(sb / (sdt * n_diff), 5), "unit": "faces/s", "cores": torch.get_num_threads(), "kind": "port",
