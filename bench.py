@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
 import torch  # noqa: E402
 
 SURVEY_WEIGHT_BYTES = {16: 722.66e6, 32: 790.28e6}      # effective params x 2 B
@@ -79,7 +80,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("HD_BENCH_FORCE_DIST"))     # FORCE: rehearse the N>1 code path with one rank
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -116,7 +118,7 @@ def main():
     Lh = _lib.lib()
     Lh.hd_set_profiling(model.engine.ctx, 1)
 
-    gathered = [torch.empty_like(x) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty_like(x) for _ in range(world)] if use_dist else None
     if os.environ.get("HD_DUMP_OPS") and rank == 0:         # op order of one captured step, for tools/prof_summary.py
         model.prepare(crf, crl)
         with open(os.environ["HD_DUMP_OPS"], "w") as f:
@@ -125,12 +127,12 @@ def main():
 
     def one_pass(seed):
         out = sampling.sample(model, x, crf, crl, sch, noise=None, seed=seed)
-        if world > 1:
+        if use_dist:
             dist.all_gather(gathered, out)                 # result gather over RCCL/xGMI (4 KB per face)
         return out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -148,7 +150,7 @@ def main():
     wbytes, fl = ctypes.c_int64(), ctypes.c_double()
     Lh.hd_get_profile(model.engine.ctx, ctypes.byref(loop_ms), ctypes.byref(step_ms_avg), ctypes.byref(wbytes), ctypes.byref(fl))
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     finite = bool(torch.isfinite(out).all().item())
@@ -192,7 +194,7 @@ def main():
                           "%d evaluations after 1 warm-up: %.3f s per diffusion step, extrapolated x%d steps"
                           % (sb, sn, sdt, n_diff)}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
