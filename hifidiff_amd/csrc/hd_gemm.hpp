@@ -507,7 +507,7 @@ __device__ __forceinline__ float activate(float v, int act) {
     if (act == 2) return 1.0f / (1.0f + expf(-v));
     return v;
 }
-struct ColC { float bias, bias2, rscale; };
+struct ColC { float bias, bias2, rscale, rscale2; };
 
 // out(fp32)[row][col] = act(acc + bias)
 struct EpBiasF32 {
@@ -562,6 +562,41 @@ struct EpGateBF16 {
     static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
     static __device__ __forceinline__ void store2(const GemmP& p, int row, int col, float v1, float v2, const ColC& c) {
         reinterpret_cast<unsigned short*>(p.out)[(size_t)row * p.ldo + col] = f32_to_bf16_bits((v1 + c.bias) * (v2 + c.bias2));
+    }
+};
+// PAIR, faces of ONE pixel (middle level at latent 16): the depthwise 3x3 sees only its centre tap, the pool is the
+// value itself, so conv1 -> conv2 -> SimpleGate -> pool is element-wise on the two accumulators:
+//   g = (b2[j] + w2[j][centre] * (acc1 + b1[j])) * (b2[j+C] + w2[j+C][centre] * (acc2 + b1[j+C]))
+struct EpDwGate1 {
+    static constexpr bool kStats = false, kTile = false;
+    static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) {
+        // fold: g = (A1 + wa * acc1) * (A2 + wb * acc2) with A = b2 + w * b1
+        const int C2 = p.N >> 1;
+        const float wa = p.dw_w[(size_t)col * 9 + 4], wb = p.dw_w[(size_t)(col + C2) * 9 + 4];
+        ColC c; c.bias = p.dw_b[col] + wa * p.bias[col]; c.bias2 = p.dw_b[col + C2] + wb * p.bias[col + C2];
+        c.rscale = wa; c.rscale2 = wb;
+        return c;
+    }
+    static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
+    static __device__ __forceinline__ void store2(const GemmP& p, int row, int col, float v1, float v2, const ColC& c) {
+        // same operation order as the tile path: t1 = acc + b1; u = b2 + w * t1 is evaluated as (b2 + w*b1) + w*acc
+        const float g = fmaf(c.rscale, v1, c.bias) * fmaf(c.rscale2, v2, c.bias2);
+        const size_t o = (size_t)row * p.ldo + col;
+        reinterpret_cast<unsigned short*>(p.out)[o] = f32_to_bf16_bits(g);
+        p.pooled[o] = g;                                          // one pixel per face: row == face
+        if (p.pooled16) p.pooled16[o] = f32_to_bf16_bits(g);
+    }
+};
+// SCA at one pixel per face: s = acc + bias and G[face][col] <- bf16(G * s), element-wise (pre() fetches G early)
+struct EpSca1BF16 {
+    static constexpr bool kStats = false, kTile = false;
+    static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = 0.f; c.rscale = 1.f; c.rscale2 = 0.f; return c; }
+    static __device__ __forceinline__ float pre(const GemmP& p, int row, int col) { return bf16_bits_to_f32(p.scale_G[(size_t)row * p.ldo + col]); }
+    static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float g, const ColC& c) {
+        v += c.bias;
+        reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
+        p.scale_G[(size_t)row * p.ldo + col] = f32_to_bf16_bits(g * v);
+        return v;
     }
 };
 // 1x1 conv (no bias) -> PixelShuffle(r) -> + skip.  For r = 2 the weight columns are packed sub-pixel major

@@ -380,7 +380,11 @@ hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
 bool dwgate_ok(int hw) { return hw == 1 || hw == 4 || hw == 16 || hw == 64 || hw == 256; }
 
 hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStream_t s) {
-    if (lk == LK_LN && ek == EK_DWGATE) return dispatch_dwgate(p, s);
+    if (lk == LK_LN && ek == EK_DWGATE) {
+        static const bool no_dw1 = getenv("HD_NO_DW1") != nullptr;
+        if (p.hw == 1 && !no_dw1) return launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate1>(p, s);   // one pixel per face: element-wise
+        return dispatch_dwgate(p, s);
+    }
     if (lk == LK_LN && ek == EK_BIASF32) return launch_tile<LdF32LN, EpBiasF32, false>(p, mode, s);
     if (lk == LK_LN && ek == EK_GATE) return launch_tile<LdF32LN, EpGateBF16, true>(p, mode, s);
     if (lk == LK_F32 && ek == EK_BIASF32) return launch_tile<LdF32Plain, EpBiasF32, false>(p, mode, s);
@@ -390,7 +394,11 @@ hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStre
     if (lk == LK_BF16 && ek == EK_BIASBF16) return launch_tile<LdBF16Plain, EpBiasBF16, false>(p, mode, s);
     if (lk == LK_CONV_BF16 && ek == EK_BIASF32) return launch_tile<LdConv<true, false>, EpBiasF32, false>(p, mode, s);
     if (lk == LK_BF16 && ek == EK_PIXSHUF) return launch_tile<LdBF16Plain, EpPixShufF32, false>(p, mode, s);
-    if (lk == LK_BF16 && ek == EK_SCA) return launch_skinny_auto<1, 1, false, LdBF16Plain, EpScaBF16>(p, s);   // its in-place G scaling is a skinny tile epilogue
+    if (lk == LK_BF16 && ek == EK_SCA) {
+        static const bool no_dw1 = getenv("HD_NO_DW1") != nullptr;
+        if (p.scale_hw == 1 && !no_dw1) return launch_skinny_auto<1, 1, false, LdBF16Plain, EpSca1BF16>(p, s);
+        return launch_skinny_auto<1, 1, false, LdBF16Plain, EpScaBF16>(p, s);   // its in-place G scaling is a skinny tile epilogue
+    }
     if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, mode, s);
     return hipErrorInvalidValue;
 }
