@@ -512,7 +512,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         }
     }
     static const bool no_chain = getenv("HD_NO_CHAIN") != nullptr;
-    if ((C == 128 || C == 256) && HW % 32 == 0 && dwgate_ok(HW) && !no_fuse && !no_chain) {
+    if ((C == 128 || C == 256) && HW % 32 == 0 && !no_fuse && !no_chain) {        // also behind the unfused depthwise path (latent 32, level 0)
         // levels 0/1: sca -> conv3 -> residual -> LN+FiLM -> conv4 -> gate -> conv5 -> residual in ONE launch (hd_chain.hpp)
         ChainP q{};
         q.M = M; q.hw = HW; q.face0 = c->ch->face0;
