@@ -168,6 +168,54 @@ def refiner_manifest(latent_res=16):
     return o
 
 
+CR_WIDTH = 32                       # models/cr/model.py:38
+CR_ENC = (2, 2, 4, 8)               # NAF blocks per encoder stage (models/cr/model.py:61-66)
+CR_MID = 8
+CR_DEC = (2, 2, 2, 2)
+
+
+def _stn(out, p, c, res):
+    """STNBlock(in_ch, in_res) (models/cr/stn.py:9-41): two valid convs with 2x2 max-pools, two Linears."""
+    k0, k1 = (3, 1) if res <= 8 else (5, 3) if res <= 16 else (7, 5) if res <= 32 else (9, 7)
+    fc_res = (res - k0 - 2 * k1 + 3) // 4
+    fc = 10 * fc_res * fc_res
+    _conv(out, p + ".localization.0", 8, c, k0, k0)
+    _conv(out, p + ".localization.3", 10, 8, k1, k1)
+    _linear(out, p + ".fc_loc.0", int(fc ** 0.5), fc)
+    _linear(out, p + ".fc_loc.2", 6, int(fc ** 0.5))
+
+
+def cr_stages():
+    """(name, channels, resolution, naf blocks, sampling) of the nine NAF_STN_Blocks in execution order."""
+    st = []
+    c, r = CR_WIDTH, 128
+    for i, n in enumerate(CR_ENC):
+        st.append((f"encoders.{i}", c, r, n, "down"))
+        c, r = c * 2, r // 2
+    st.append(("middle_blocks", c, r, CR_MID, None))
+    for i, n in enumerate(CR_DEC):
+        st.append((f"decoders.{i}", c, r, n, "up"))
+        c, r = c // 2, r * 2
+    return st
+
+
+def cr_manifest(prefix=""):
+    """CoarseRestoration().state_dict() (models/cr/model.py:33-71), registration order."""
+    o = OrderedDict()
+    q = prefix + "." if prefix else ""
+    _conv(o, q + "intro", CR_WIDTH, 3, 3, 3)
+    _conv(o, q + "outro", 3, CR_WIDTH, 3, 3)
+    for name, c, r, n, samp in cr_stages():
+        for j in range(n):
+            _naf_block(o, f"{q}{name}.nfbs.{j}", c, None)
+        _stn(o, f"{q}{name}.stn", c, r)
+        if samp == "down":
+            _conv(o, f"{q}{name}.sampling", 2 * c, c, 2, 2)
+        elif samp == "up":
+            _conv(o, f"{q}{name}.sampling.0", 2 * c, c, 1, 1, bias=False)
+    return o
+
+
 def naf_levels(latent_res):
     """(channels, side) of the five UNet levels: C_l = 128*2^l, side = L/2^l."""
     return [(WIDTH << l, latent_res >> l) for l in range(5)]

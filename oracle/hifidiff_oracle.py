@@ -353,6 +353,54 @@ def denoiser_uncond(P, latents, timesteps, prec=FP32, prefix="denoiser", taps=No
     return x
 
 
+# ------------------------------------------------------------------------- CoarseRestoration (f1)
+def stn_theta(P, p, x):
+    """Localisation network of STNBlock -> theta (B,2,3) (models/cr/stn.py:22-48).  fp32 throughout: the
+    affine parameters steer a resampling grid, so the HIP path keeps this small network out of bf16 as well."""
+    xs = F.conv2d(x, P[p + ".localization.0.weight"], P[p + ".localization.0.bias"])
+    xs = torch.relu(F.max_pool2d(xs, 2, stride=2))
+    xs = F.conv2d(xs, P[p + ".localization.3.weight"], P[p + ".localization.3.bias"])
+    xs = torch.relu(F.max_pool2d(xs, 2, stride=2))
+    xs = xs.reshape(x.shape[0], -1)
+    h = torch.relu(F.linear(xs, P[p + ".fc_loc.0.weight"], P[p + ".fc_loc.0.bias"]))
+    return F.linear(h, P[p + ".fc_loc.2.weight"], P[p + ".fc_loc.2.bias"]).reshape(-1, 2, 3)
+
+
+def stn_block(P, p, x, taps=None):
+    """STNBlock.forward: affine_grid + bilinear grid_sample, align_corners=False, zero padding (stn.py:43-52)."""
+    theta = stn_theta(P, p, x)
+    _tap(taps, p + ".theta", theta)
+    grid = F.affine_grid(theta, list(x.shape), align_corners=False)
+    y = F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    _tap(taps, p, y)
+    return y
+
+
+def coarse_restoration(P, x, prec=FP32, prefix="", taps=None):
+    """CoarseRestoration.forward (models/cr/model.py:73-88): (B,3,128,128) -> (B,3,128,128)."""
+    from hifidiff_amd import arch
+    q = prefix + "." if prefix else ""
+    x = F.conv2d(x, P[q + "intro.weight"], P[q + "intro.bias"], padding=1)
+    _tap(taps, q + "intro", x)
+    skips = []
+    for name, c, r, n, samp in arch.cr_stages():
+        sp = q + name
+        if name.startswith("decoders"):
+            x = x + skips.pop()                                   # model.py:82-83: x = x + enc_skip, then the stage
+        for j in range(n):
+            x = naf_block(P, f"{sp}.nfbs.{j}", x, prec, taps)
+        x = stn_block(P, sp + ".stn", x, taps)
+        if samp == "down":
+            x = _gemm_conv(x, P[sp + ".sampling.weight"], P[sp + ".sampling.bias"], prec, stride=2)
+            skips.append(x)                                       # model.py:77-79: the skip is the stage OUTPUT
+        elif samp == "up":
+            x = _up_shuffle(x, P[sp + ".sampling.0.weight"], 2, prec)
+        _tap(taps, sp, x)
+    x = F.conv2d(x, P[q + "outro.weight"], P[q + "outro.bias"], padding=1)
+    _tap(taps, q + "outro", x)
+    return x
+
+
 def refiner_forward(P, latents, timesteps, cr_face, cr_latent, prec=FP32):
     """FacialRefiner.forward as written: FPG and IDC recomputed on every call (models/refiner.py:32-38)."""
     priors = fpg(P, cr_latent, "fpg", prec)

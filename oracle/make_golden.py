@@ -85,6 +85,34 @@ def gen_uncond(args):
 
 
 @torch.no_grad()
+def gen_cr(args):
+    """CoarseRestoration (models/cr/model.py:33-88) on two synthetic 128x128 faces: output, the nine STN thetas and
+    the stage outputs.  The synthetic fc_loc.2 weights are scaled down so that theta stays near the identity the
+    reference initialises it to (stn.py:38-41) instead of sampling mostly outside the image."""
+    import_reference(args.ref)
+    from models.cr.model import CoarseRestoration
+    sd = synth.cr_state_dict()
+    net = CoarseRestoration().eval()
+    net.load_state_dict(sd, strict=True)
+    x = T(np.stack([synth.rand(f"ln_face/{f}", (3, 128, 128)) for f in range(2)]))
+    out = {"out": net(x).numpy()}
+    # stage taps through forward hooks: thetas and stage outputs
+    feats = {}
+    h = net.intro(x)
+    skips = []
+    for i, enc in enumerate(net.encoders):
+        h = enc(h); skips.append(h); feats[f"encoders.{i}"] = h
+    h = net.middle_blocks(h); feats["middle_blocks"] = h
+    for i, (dec, sk) in enumerate(zip(net.decoders, skips[::-1])):
+        h = dec(h + sk); feats[f"decoders.{i}"] = h
+    assert torch.equal(net.outro(h), torch.from_numpy(out["out"]))
+    for k in ("encoders.3", "middle_blocks"):                      # small maps only: the fixture stays < 1 MB
+        out["feat." + k] = feats[k].numpy()
+    np.savez_compressed(os.path.join(args.out, "coarse_restoration.npz"), **out)
+    print("wrote coarse_restoration.npz", {k: v.shape for k, v in out.items()})
+
+
+@torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -96,6 +124,8 @@ def main():
     torch.manual_seed(0)
     if args.only == "uncond":
         return gen_uncond(args)
+    if args.only == "cr":
+        return gen_cr(args)
     FacialRefiner, CondBlock, PosEmb, HCA = import_reference(args.ref)
 
     t0 = time.time()

@@ -120,3 +120,16 @@ def test_unconditional_denoiser(weights16):
         assert rel_l2(O.denoiser_uncond(weights16, x, torch.from_numpy(g[f"t{i}"])), g[f"eps{i}"]) <= TOL32, i
     assert rel_l2(O.denoiser_uncond(weights16, x, 321), g["eps_scalar_t"]) <= TOL32
     assert rel_l2(O.denoiser_uncond(weights16, x, torch.from_numpy(g["t1"]), prec=O.BF16), g["eps1"]) <= 1e-2
+
+
+def test_coarse_restoration():
+    """CoarseRestoration (models/cr/model.py:33-88, STN models/cr/stn.py) restated, against the
+    reference's own output and stage features."""
+    g = golden("coarse_restoration.npz")
+    P = synth.cr_state_dict()
+    x = torch.from_numpy(np.stack([synth.rand(f"ln_face/{f}", (3, 128, 128)) for f in range(2)]))
+    taps = {}
+    assert rel_l2(O.coarse_restoration(P, x, taps=taps), g["out"]) <= TOL32
+    for k in ("encoders.3", "middle_blocks"):
+        assert rel_l2(taps[k], g["feat." + k]) <= TOL32, k
+    assert rel_l2(O.coarse_restoration(P, x, prec=O.BF16), g["out"]) <= 1e-2
