@@ -190,7 +190,9 @@ struct LdF32Plain {
         st.rowp = reinterpret_cast<const float*>(p.A) + (size_t)(st.valid ? row : 0) * p.lda;
     }
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
-        r.x = (st.valid && kc < p.K) ? ldg44(st.rowp + kc + 4 * kq) : zero8();
+        // K is a multiple of 8, not necessarily of 64 (CoarseRestoration level 0: K = 32): each half is checked
+        if (st.valid && kc + 32 + 4 * kq < p.K) r.x = ldg44(st.rowp + kc + 4 * kq);
+        else { r.x = zero8(); if (st.valid && kc + 4 * kq < p.K) r.x.a = *reinterpret_cast<const float4*>(st.rowp + kc + 4 * kq); }
     }
     static __device__ __forceinline__ uint4 finish(const GemmP& p, const St&, int, int, const Raw& r) {
         float v[8]; f8_to_arr(r.x, v);
@@ -352,11 +354,11 @@ struct LdF32LN {
         st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
     }
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
-        r.x = (st.valid && kc < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
+        r.x = (st.valid && kc + 8 * kq < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
     }
     static __device__ __forceinline__ uint4 finish(const GemmP& p, const St& st, int kc, int kq, const Raw& r) {
         float v[8], g[8], b[8];
-        if (!(st.valid && kc < p.K)) return make_uint4(0, 0, 0, 0);
+        if (!(st.valid && kc + 8 * kq < p.K)) return make_uint4(0, 0, 0, 0);
         unpack8(r.x, v);
         const int k = kc + 8 * kq;
         const float* gp = st.gbl ? st.gbl + k : st.gain + k;
@@ -387,7 +389,7 @@ struct LdBF16Plain {
         st.rowp = reinterpret_cast<const unsigned short*>(p.A) + (size_t)(st.valid ? row : 0) * p.lda;
     }
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
-        r.x = (st.valid && kc < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
+        r.x = (st.valid && kc + 8 * kq < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
     }
     static __device__ __forceinline__ uint4 finish(const GemmP&, const St&, int, int, const Raw& r) { return r.x; }
 };
@@ -410,7 +412,7 @@ struct LdBF16Scale {
         st.srow = p.rowscale + (size_t)(r / p.hw) * p.K;
     }
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
-        const bool ok = st.valid && kc < p.K;
+        const bool ok = st.valid && kc + 8 * kq < p.K;
         r.x = ok ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
         F8 s;
         s.a = ok ? *reinterpret_cast<const float4*>(st.srow + kc + 8 * kq) : make_float4(0, 0, 0, 0);

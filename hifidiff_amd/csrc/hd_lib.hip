@@ -16,6 +16,7 @@
 #include "../../include/hifidiff_hip.h"
 #include "hd_chain.hpp"
 #include "hd_conv.hpp"
+#include "hd_cr.hpp"
 #include "hd_gemm.hpp"
 #include "hd_kernels.hpp"
 
@@ -99,6 +100,16 @@ static std::string g_create_error;
 struct hd_ctx {
     int L = 16, device = 0, S = 1;            // S = L/16
     bool conditional = true;                  // false: the unconditional Denoiser (models/denoiser/model.py:32-134): no priors, HCAs or IDC
+    bool cr = false;                          // true: this context holds the CoarseRestoration network and nothing else
+    struct CrStage { std::string name; int C, H, nblk, samp, level; };   // samp: 0 none, 1 down, 2 up
+    std::vector<CrStage> cr_stages;
+    std::vector<BlockW> cr_blocks;            // execution order
+    PackedW cr_samp[9];                       // per stage: down (2x2 s2) or up (1x1 + PixelShuffle) conv
+    float* cr_ln_pack = nullptr;
+    float* cr_skip[5] = {};                   // encoder-stage outputs kept for the decoder adds (levels 1..4)
+    float *cr_loc1 = nullptr, *cr_loc2 = nullptr, *cr_theta = nullptr;   // STN temporaries
+    std::vector<Op> cr_program;
+    const float* cr_in = nullptr; float* cr_out = nullptr;
     std::string err;
     std::unordered_map<std::string, RawTensor> raw;
     std::vector<void*> allocs;
@@ -261,6 +272,38 @@ std::vector<std::pair<std::string, Shape>> build_manifest(int L, bool conditiona
     for (int i = 0; i < 4; ++i) { m_conv(m, f + ".downs." + std::to_string(i), 2 * c, c, 2, 2); c *= 2; }
     m_conv(m, f + ".convs.0.0", c, c, 1, 1, false);
     for (int i = 1; i < 5; ++i) { m_conv(m, f + ".convs." + std::to_string(i) + ".0", c * 2, c, 1, 1, false); c /= 2; }
+    return m;
+}
+
+// CoarseRestoration().state_dict() (models/cr/model.py:33-71): mirrors hifidiff_amd/arch.py cr_manifest.
+static void cr_stage_list(std::vector<hd_ctx::CrStage>& st) {
+    st.clear();
+    const int enc[4] = {2, 2, 4, 8};
+    int C = 32, H = 128;
+    for (int i = 0; i < 4; ++i) { st.push_back({"encoders." + std::to_string(i), C, H, enc[i], 1, i}); C *= 2; H /= 2; }
+    st.push_back({"middle_blocks", C, H, 8, 0, 4});
+    for (int i = 0; i < 4; ++i) { st.push_back({"decoders." + std::to_string(i), C, H, 2, 2, 4 - i}); C /= 2; H *= 2; }
+}
+static void stn_shape(int res, int* k0, int* k1, int* fc) {
+    if (res <= 8) { *k0 = 3; *k1 = 1; } else if (res <= 16) { *k0 = 5; *k1 = 3; } else if (res <= 32) { *k0 = 7; *k1 = 5; } else { *k0 = 9; *k1 = 7; }
+    const int fr = (res - *k0 - 2 * *k1 + 3) / 4;
+    *fc = 10 * fr * fr;
+}
+std::vector<std::pair<std::string, Shape>> build_cr_manifest() {
+    std::vector<std::pair<std::string, Shape>> m;
+    m_conv(m, "intro", 32, 3, 3, 3); m_conv(m, "outro", 3, 32, 3, 3);
+    std::vector<hd_ctx::CrStage> st;
+    cr_stage_list(st);
+    for (const auto& g : st) {
+        for (int j = 0; j < g.nblk; ++j) m_naf(m, g.name + ".nfbs." + std::to_string(j), g.C, false);
+        int k0, k1, fc;
+        stn_shape(g.H, &k0, &k1, &fc);
+        const int n1 = (int)std::sqrt((double)fc);
+        m_conv(m, g.name + ".stn.localization.0", 8, g.C, k0, k0); m_conv(m, g.name + ".stn.localization.3", 10, 8, k1, k1);
+        m_lin(m, g.name + ".stn.fc_loc.0", n1, fc); m_lin(m, g.name + ".stn.fc_loc.2", 6, n1);
+        if (g.samp == 1) m_conv(m, g.name + ".sampling", 2 * g.C, g.C, 2, 2);
+        else if (g.samp == 2) m_conv(m, g.name + ".sampling.0", 2 * g.C, g.C, 1, 1, false);
+    }
     return m;
 }
 
@@ -701,6 +744,204 @@ int run_ops(hd_ctx* c, std::vector<Op>& prog, hipStream_t s, int limit = -1) {
     return HD_OK;
 }
 
+
+// =============================================================================== CoarseRestoration (§8 f1)
+// models/cr/model.py:73-88: intro -> 4 x [NAF blocks, STN, down] (stage outputs are the skips) -> [8 NAF, STN]
+// -> 4 x [(+ skip), NAF blocks, STN, up] -> outro.  Stage s works on level buffers of its own geometry
+// (C = 32 << level, side 128 >> level); NAF blocks, down- and up-convs are the refiner path's launches.
+static int load_naf_block(hd_ctx* c, const std::string& p, int C, BlockW& bw) {
+    bw.name = p; bw.C = C;
+    int r = 0;
+    r |= pack_weight(c, p + ".conv1", &bw.conv1); r |= pack_weight(c, p + ".conv3", &bw.conv3);
+    r |= pack_weight(c, p + ".sca.1", &bw.sca); r |= pack_weight(c, p + ".conv4", &bw.conv4);
+    r |= pack_weight(c, p + ".conv5", &bw.conv5);
+    if (r) return r;
+    bw.dw_w = find_raw(c, p + ".conv2.weight")->dev; bw.dw_b = find_raw(c, p + ".conv2.bias")->dev;
+    bw.beta = find_raw(c, p + ".beta")->dev; bw.gamma = find_raw(c, p + ".gamma")->dev;
+    return HD_OK;
+}
+
+static int finalize_cr(hd_ctx* c) {
+    const auto man = build_cr_manifest();
+    for (const auto& e : man) {
+        const RawTensor* r = find_raw(c, e.first);
+        if (!r) HD_FAIL(c, HD_ERR_WEIGHTS, "Missing key in state_dict: %s", e.first.c_str());
+        if (r->shape != e.second) HD_FAIL(c, HD_ERR_WEIGHTS, "size mismatch for %s", e.first.c_str());
+    }
+    if (c->raw.size() != man.size()) {
+        std::unordered_map<std::string, int> known;
+        for (const auto& e : man) known[e.first] = 1;
+        for (const auto& kv : c->raw)
+            if (!known.count(kv.first)) HD_FAIL(c, HD_ERR_WEIGHTS, "Unexpected key in state_dict: %s", kv.first.c_str());
+    }
+    cr_stage_list(c->cr_stages);
+    int rc = 0, off = 0;
+    for (size_t si = 0; si < c->cr_stages.size(); ++si) {
+        const auto& g = c->cr_stages[si];
+        for (int j = 0; j < g.nblk; ++j) {
+            BlockW bw;
+            rc = load_naf_block(c, g.name + ".nfbs." + std::to_string(j), g.C, bw);
+            if (rc) return rc;
+            bw.film_off = off; off += 4 * g.C;
+            c->cr_blocks.push_back(bw);
+        }
+        if (g.samp == 1) rc = pack_weight(c, g.name + ".sampling", &c->cr_samp[si]);
+        else if (g.samp == 2) { PackOpts o; o.S2 = 4; rc = pack_weight(c, g.name + ".sampling.0", &c->cr_samp[si], o); }   // sub-pixel major (EpPixShufF32)
+        if (rc) return rc;
+    }
+    rc = dev_alloc(c, &c->cr_ln_pack, (size_t)off);
+    if (rc) return rc;
+    const char* names[4] = {".norm1.bias", ".norm1.weight", ".norm2.bias", ".norm2.weight"};     // table layout [bias | gain] per norm
+    for (const BlockW& bw : c->cr_blocks)
+        for (int q = 0; q < 4; ++q)
+            HIPCHECK(c, hipMemcpy(c->cr_ln_pack + bw.film_off + q * bw.C, find_raw(c, bw.name + names[q])->dev, bw.C * sizeof(float), hipMemcpyDeviceToDevice));
+    HIPCHECK(c, hipDeviceSynchronize());
+    c->finalized = true;
+    return HD_OK;
+}
+
+static void add_stn(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Level& lv, int B) {
+    int k0, k1, fc;
+    stn_shape(lv.H, &k0, &k1, &fc);
+    const int n1 = (int)std::sqrt((double)fc);
+    const int H1p = (lv.H - k0 + 1) / 2, H2p = (H1p - k1 + 1) / 2;
+    const float *w0 = find_raw(c, name + ".localization.0.weight")->dev, *b0 = find_raw(c, name + ".localization.0.bias")->dev;
+    const float *w3 = find_raw(c, name + ".localization.3.weight")->dev, *b3 = find_raw(c, name + ".localization.3.bias")->dev;
+    const float *f0w = find_raw(c, name + ".fc_loc.0.weight")->dev, *f0b = find_raw(c, name + ".fc_loc.0.bias")->dev;
+    const float *f2w = find_raw(c, name + ".fc_loc.2.weight")->dev, *f2b = find_raw(c, name + ".fc_loc.2.bias")->dev;
+    float *loc1 = c->cr_loc1, *loc2 = c->cr_loc2, *theta = c->cr_theta;
+    const float* X = lv.X; float* Y = lv.Y; unsigned short* Yb = lv.Yb;
+    const int C = lv.C, H = lv.H;
+    {   // localization[0..2]: conv k0 (valid) on the channels-last map -> maxpool 2 -> relu
+        StnConvP q{};
+        q.in = X; q.sb = (long long)H * H * C; q.sc = 1; q.sy = (long long)H * C; q.sx = C;
+        q.w = w0; q.bias = b0; q.out = loc1; q.B = B; q.Cin = C; q.Hin = H; q.k = k0; q.Cout = 8; q.Hp = H1p;
+        const long long total = (long long)B * 8 * H1p * H1p;
+        prog.push_back({name + ".localization.0", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(stn_conv_pool_relu_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, q);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = loc1; prog.back().out_elems = (size_t)total;
+    }
+    {   // localization[3..5]: conv k1 on the NCHW result -> maxpool 2 -> relu
+        StnConvP q{};
+        q.in = loc1; q.sb = (long long)8 * H1p * H1p; q.sc = (long long)H1p * H1p; q.sy = H1p; q.sx = 1;
+        q.w = w3; q.bias = b3; q.out = loc2; q.B = B; q.Cin = 8; q.Hin = H1p; q.k = k1; q.Cout = 10; q.Hp = H2p;
+        const long long total = (long long)B * 10 * H2p * H2p;
+        prog.push_back({name + ".localization.3", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(stn_conv_pool_relu_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, q);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = loc2; prog.back().out_elems = (size_t)total;
+    }
+    prog.push_back({name + ".theta", [=](hipStream_t s) -> hipError_t {
+                        hipLaunchKernelGGL(stn_fc_kernel, dim3(B), dim3(256), 0, s, loc2, fc, f0w, f0b, n1, f2w, f2b, theta);
+                        return hipGetLastError();
+                    }});
+    prog.back().out = theta; prog.back().out_elems = (size_t)B * 6;
+    prog.push_back({name, [=](hipStream_t s) -> hipError_t {
+                        const size_t n = (size_t)B * H * H * (C / 4);
+                        hipLaunchKernelGGL(stn_grid_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, theta, Y, Yb, B, H, C);
+                        return hipGetLastError();
+                    }});
+    prog.back().out = Y; prog.back().out_elems = (size_t)lv.M * C;
+}
+
+static int alloc_cr(hd_ctx* c, int B) {
+    if (B == c->B) return HD_OK;
+    if (c->B != 0) HD_FAIL(c, HD_ERR_INVALID, "batch size change (%d -> %d) needs a new context", c->B, B);
+    c->chains.resize(1);
+    Chain& ch = c->chains[0];
+    ch.index = 0; ch.B = B; ch.face0 = 0;
+    int rc = 0;
+    for (int l = 0; l < 5; ++l) {
+        Level& v = ch.lv[l];
+        v.C = 32 << l; v.H = 128 >> l; v.M = B * v.H * v.H;
+        const size_t mc = (size_t)v.M * v.C;
+        rc |= dev_alloc(c, &v.X, mc); rc |= dev_alloc(c, &v.Y, mc); rc |= dev_alloc(c, &v.T1, 2 * mc + (size_t)B * ((v.H + 7) / 8) * v.C);
+        rc |= dev_alloc(c, &v.G, mc); rc |= dev_alloc(c, &v.pooled, (size_t)B * v.C); rc |= dev_alloc(c, &v.S, (size_t)B * v.C);
+        rc |= dev_alloc(c, &v.sx, (size_t)v.M * (v.C / 32)); rc |= dev_alloc(c, &v.sy, (size_t)v.M * (v.C / 32));
+        rc |= dev_alloc(c, &v.Xb, mc); rc |= dev_alloc(c, &v.Yb, mc); rc |= dev_alloc(c, &v.Xg, 64);
+        rc |= dev_alloc(c, &v.pooled16, (size_t)B * v.C);
+        if (l > 0) rc |= dev_alloc(c, &c->cr_skip[l], mc);
+        if (rc) return rc;
+    }
+    // STN temporaries sized for the largest stage (side 128: 8 x 60 x 60 and 10 x 27 x 27 per face)
+    rc |= dev_alloc(c, &c->cr_loc1, (size_t)B * 8 * 60 * 60); rc |= dev_alloc(c, &c->cr_loc2, (size_t)B * 10 * 27 * 27);
+    rc |= dev_alloc(c, &c->cr_theta, (size_t)B * 6);
+    rc |= dev_alloc(c, &ch.step_state, 1);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemset(ch.step_state, 0, sizeof(StepState)));
+    c->B = B;
+    c->ch = &ch;
+    return HD_OK;
+}
+
+// in / out: [B,3,128,128] fp32 NCHW device pointers of this call (captured by the first and last op)
+static int build_cr_program(hd_ctx* c, const float* in, float* out) {
+    std::vector<Op>& prog = c->cr_program;
+    prog.clear();
+    Chain& ch = c->chains[0];
+    const int B = ch.B;
+    {
+        const float *w = find_raw(c, "intro.weight")->dev, *b = find_raw(c, "intro.bias")->dev;
+        float* X = ch.lv[0].X; unsigned short* Xb = ch.lv[0].Xb; float2* sx = ch.lv[0].sx;
+        const size_t M = (size_t)ch.lv[0].M;
+        prog.push_back({"intro", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(cr_intro_kernel, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, s, in, w, b, X, Xb, sx, B, 128);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = X; prog.back().out_elems = M * 32;
+    }
+    int np = 1, cnt = 32, bi = 0;
+    for (size_t si = 0; si < c->cr_stages.size(); ++si) {
+        const auto& g = c->cr_stages[si];
+        const Level& lv = ch.lv[g.level];
+        if (si == 5) {
+            // decoders.0 input: middle output (STN result in Y) + skip of level 4 (model.py:82-83); later decoder inputs
+            // get their skip added by the preceding up-conv epilogue
+            const float *A = lv.Y, *S = c->cr_skip[4]; float* X = lv.X; unsigned short* Xb = lv.Xb; float2* sx = lv.sx;
+            const int M = lv.M, C = lv.C;
+            prog.push_back({g.name + ".skip_add", [=](hipStream_t s) -> hipError_t {
+                                hipLaunchKernelGGL(add_rows_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, A, S, X, Xb, sx, M, C);
+                                return hipGetLastError();
+                            }});
+            prog.back().out = X; prog.back().out_elems = (size_t)M * C;
+            np = 1; cnt = C;
+        }
+        for (int j = 0; j < g.nblk; ++j) add_naf_block(c, prog, c->cr_blocks[bi++], lv, c->cr_ln_pack, &np, &cnt);
+        add_stn(c, prog, g.name + ".stn", lv, B);
+        if (g.samp == 1) {
+            const Level& dst = ch.lv[g.level + 1];
+            GemmP p = base_gemm(c->cr_samp[si], dst.M);           // Conv2d(C, 2C, 2, 2) on the STN output (bf16 copy in Yb)
+            p.A = lv.Yb; p.lda = lv.C; p.Hin = lv.H; p.Win = lv.H; p.Cin = lv.C; p.KH = 2; p.KW = 2; p.stride = 2; p.pad = 0;
+            p.Hout = dst.H; p.Wout = dst.H; p.ntaps = 4;
+            p.out = dst.X; p.ldo = dst.C; p.stats_out = dst.sx; p.out16 = dst.Xb;
+            add_gemm(c, prog, g.name, p, LK_CONV_BF16, EK_BIASF32);
+            float* skip = c->cr_skip[g.level + 1]; const float* src = dst.X; const size_t bytes = (size_t)dst.M * dst.C * sizeof(float);
+            prog.push_back({g.name + ".skip_copy", [=](hipStream_t s) -> hipError_t { return hipMemcpyAsync(skip, src, bytes, hipMemcpyDeviceToDevice, s); }});
+            np = dst.C / 32; cnt = 32;
+        } else if (g.samp == 2) {
+            const Level& lo = ch.lv[g.level - 1];
+            add_up(c, prog, g.name, c->cr_samp[si], lv.Yb, true, lv.M, lv.H, lv.C, lo.X, g.level - 1 >= 1 ? c->cr_skip[g.level - 1] : nullptr, 2, lo.Xb, lo.sx);
+            np = lo.C / 32; cnt = 32;
+        } else {
+            prog.back().name = g.name;                             // middle stage: its output is the STN result
+        }
+    }
+    {
+        const float *X = ch.lv[0].X, *w = find_raw(c, "outro.weight")->dev, *b = find_raw(c, "outro.bias")->dev;
+        const size_t M = (size_t)ch.lv[0].M;
+        prog.push_back({"outro", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(cr_outro_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, X, w, b, out, B, 128);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = out; prog.back().out_elems = M * 3;
+    }
+    c->cr_in = in; c->cr_out = out;
+    return HD_OK;
+}
+
 // --------------------------------------------------------------------------------------- workspace
 int alloc_chain(hd_ctx* c, Chain& ch) {
     const int L = c->L, B = ch.B;
@@ -1024,6 +1265,28 @@ int hd_create_unconditional(hd_ctx** out, int latent_res, int device) {
     return rc;
 }
 
+int hd_cr_create(hd_ctx** out, int device) {
+    int rc = hd_create(out, 16, device);
+    if (rc == HD_OK) { (*out)->cr = true; (*out)->conditional = false; }
+    return rc;
+}
+
+// cr_face = CoarseRestoration(ln_face) (test_refiner.py:77): [B,3,128,128] fp32 NCHW in and out.
+int hd_cr_forward(hd_ctx* c, int batch, const float* ln_face, float* cr_face_out, void* stream) {
+    if (!c) return HD_ERR_INVALID;
+    if (!c->cr) HD_FAIL(c, HD_ERR_INVALID, "hd_cr_forward: not a CoarseRestoration context (hd_cr_create)");
+    if (!c->finalized) HD_FAIL(c, HD_ERR_NOT_READY, "weights are not loaded/finalized");
+    if (!ln_face || !cr_face_out || batch <= 0 || batch > 1024) HD_FAIL(c, HD_ERR_INVALID, "hd_cr_forward: bad arguments");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = alloc_cr(c, batch);
+    if (rc) return rc;
+    if (c->cr_program.empty() || c->cr_in != ln_face || c->cr_out != cr_face_out) {
+        rc = build_cr_program(c, ln_face, cr_face_out);
+        if (rc) return rc;
+    }
+    return run_ops(c, c->cr_program, reinterpret_cast<hipStream_t>(stream), c->op_limit);
+}
+
 int hd_create(hd_ctx** out, int latent_res, int device) {
     if (!out) return HD_ERR_INVALID;
     *out = nullptr;
@@ -1100,6 +1363,7 @@ int hd_finalize_weights(hd_ctx* c) {
     if (!c) return HD_ERR_INVALID;
     if (c->finalized) return HD_OK;
     HIPCHECK(c, hipSetDevice(c->device));
+    if (c->cr) return finalize_cr(c);
     // ---- strict key / shape check ----
     const auto man = build_manifest(c->L, c->conditional);
     for (const auto& e : man) {
@@ -1290,11 +1554,12 @@ static int prepare_common(hd_ctx* c, int batch) {
 }
 
 #define HD_NEED_CONDITIONAL(c, what) \
-    do { if ((c) && !(c)->conditional) HD_FAIL(c, HD_ERR_INVALID, what ": this context holds the unconditional Denoiser (no priors / identity)"); } while (0)
+    do { if ((c) && !(c)->conditional) HD_FAIL(c, HD_ERR_INVALID, what ": this context holds the unconditional Denoiser or CoarseRestoration (no priors / identity)"); } while (0)
 
 // Unconditional Denoiser: nothing to condition on -- size the workspace for `batch` faces and build the launch program.
 int hd_prepare_unconditional(hd_ctx* c, int batch, void* stream) {
     (void)stream;
+    if (c && c->cr) HD_FAIL(c, HD_ERR_INVALID, "hd_prepare_unconditional: this context holds CoarseRestoration");
     if (c && c->conditional) HD_FAIL(c, HD_ERR_INVALID, "hd_prepare_unconditional: this context holds the conditional FusedDenoiser");
     int rc = prepare_common(c, batch);
     if (rc) return rc;
@@ -1504,6 +1769,7 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
 
 static std::vector<Op>* which_program(hd_ctx* c, int which) {
     static std::vector<Op> empty;
+    if (c->cr) return &c->cr_program;
     if (c->chains.empty()) return &empty;
     return which == 0 ? &c->chains[0].program : &c->chains[0].prep_program;
 }

@@ -60,6 +60,13 @@ int hd_create(hd_ctx** out, int latent_res, int device);
  * passed with the prefix "denoiser." (denoiser.time_mlp.1.weight, denoiser.encoders.0.0.conv1.weight ...).
  * Use hd_prepare_unconditional instead of hd_prepare; hd_eps / hd_sample work as for the refiner. */
 int hd_create_unconditional(hd_ctx** out, int latent_res, int device);
+/* The coarse-restoration network that produces `cr_face` before the loop:
+ * `CoarseRestoration()` (models/cr/model.py:33-88; called as `cr_module(ln_face)` at test_refiner.py:77,
+ * infer_cr.py:48-60).  A context of its own: load its state dict (keys as in the reference, no prefix) with
+ * hd_load_weights / hd_finalize_weights, then
+ *   hd_cr_forward(ctx, B, ln_face [B,3,128,128], cr_face_out [B,3,128,128], stream). */
+int hd_cr_create(hd_ctx** out, int device);
+int hd_cr_forward(hd_ctx* ctx, int batch, const float* ln_face, float* cr_face_out, void* stream);
 void hd_destroy(hd_ctx* ctx);
 const char* hd_last_error(const hd_ctx* ctx);   /* ctx may be NULL: creation errors */
 

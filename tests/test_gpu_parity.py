@@ -294,3 +294,26 @@ def test_checkpoint_ingest(gpu, weights16, model2, inputs2, tmp_path):
     assert torch.equal(sd["fpg.encoders.0.0.conv1.weight"], weights16["denoiser.encoders.0.0.conv1.weight"])
     with pytest.raises(RuntimeError):
         m3.to("cuda:0")                                             # fpg.convs.* have no source yet: state dict incomplete
+
+
+def test_coarse_restoration_against_reference_golden(gpu):
+    """`CoarseRestoration` (32 NAF blocks + 9 STNs, models/cr/model.py:33-88) through the library:
+    output vs the reference's own output (fp32 golden) and vs the bf16-emulating oracle; a second batch size."""
+    from hifidiff_amd import synth
+    from hifidiff_amd.cr import CoarseRestoration
+    from oracle import hifidiff_oracle as O
+    g = golden("coarse_restoration.npz")
+    P = synth.cr_state_dict()
+    m = CoarseRestoration()
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in P.items() if k != "outro.bias"})       # strict: missing key
+    m.load_state_dict(P)
+    m.to("cuda:0")
+    x = T(np.stack([synth.rand(f"ln_face/{f}", (3, 128, 128)) for f in range(2)]))
+    out = m(x.cuda()).cpu()
+    assert rel_l2(out, g["out"]) <= 1e-2
+    assert rel_l2(out, O.coarse_restoration(P, x, prec=O.BF16)) <= 6e-3
+    one = m(x[:1].cuda()).cpu()                                                    # faces are independent
+    assert psnr(one, out[:1], data_range=1.0) >= 50.0
+    with pytest.raises(RuntimeError):
+        m(x[:, :, :64].cuda())                                                     # input must be 128x128
