@@ -113,30 +113,6 @@ __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict
     }
 }
 
-// (mean, M2) over the C channels of every row: LayerNorm statistics for tensors whose producer cannot
-// emit them (pixel-shuffled up-conv outputs).  One wave per row.
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ X, unsigned short* __restrict__ X16,
-                                                         float2* __restrict__ stats, int M, int C) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const float* rp = X + (size_t)row * C;
-    float s = 0.f;
-    for (int k = lane * 4; k < C; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(rp + k);
-        s += (v.x + v.y) + (v.z + v.w);
-        *reinterpret_cast<uint2*>(X16 + (size_t)row * C + k) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));   // bf16 copy for the LN GEMM
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-    for (int k = lane * 4; k < C; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(rp + k);
-        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-        q += (a * a + b * b) + (c * c + d * d);
-    }
-    q = wave_sum(q);
-    if (lane == 0) stats[row] = make_float2(mean, q);
-}
-
 // ending: Conv2d(128,4,3,pad 1) channels-last fp32 -> NCHW eps (models/denoiser/model.py:168-176,261), and --
 // in the sampling loop -- the scheduler update of the same elements (sched_update below) plus the staging of
 // the next step's FiLM row, so the step ends with this launch.

@@ -640,16 +640,6 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
     *x_np = C / 32; *x_cnt = 32;
 }
 
-void add_row_stats(std::vector<Op>& prog, const std::string& name, const float* X, unsigned short* X16, float2* stats, int M, int C) {
-    Op op;
-    op.name = name;
-    op.run = [=](hipStream_t s) -> hipError_t {
-        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, X16, stats, M, C);
-        return hipGetLastError();
-    };
-    prog.push_back(op);
-}
-
 void add_down(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const Level& src, const Level& dst) {
     GemmP p = base_gemm(w, dst.M);                      // Conv2d(C, 2C, 2, 2) as a patch-gather GEMM
     p.A = src.Xb; p.lda = src.C; p.Hin = src.H; p.Win = src.H; p.Cin = src.C; p.KH = 2; p.KW = 2; p.stride = 2; p.pad = 0;
