@@ -69,31 +69,42 @@ __global__ __launch_bounds__(256) void cr_outro_kernel(const float* __restrict__
 // STN localisation stage: valid k x k conv -> MaxPool2d(2, 2) -> ReLU (stn.py:23-30), fp32, output NCHW
 // [B][Cout][Hp][Hp] (the order .view(-1, fc_size) flattens).  The input is addressed through strides so that the
 // same kernel reads the channels-last feature map (first stage) and the NCHW output of the first stage (second).
-// One wave per pooled output element: lanes split the Cin*k*k products, DPP wave reduction.
+// One wave per pooled pixel, all COUT output channels: lanes split the Cin*k*k products (each input value is
+// loaded once for all channels), DPP wave reductions.
 struct StnConvP {
     const float* in; long long sb, sc, sy, sx;                    // element strides of the input
     const float *w, *bias;                                        // w[Cout][Cin][k][k]
     float* out;
     int B, Cin, Hin, k, Cout, Hp;                                 // Hp = (Hin - k + 1) / 2
 };
+template <int COUT>
 __global__ __launch_bounds__(256) void stn_conv_pool_relu_kernel(const StnConvP p) {
     const int lane = threadIdx.x & 63;
-    const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long total = (long long)p.B * p.Cout * p.Hp * p.Hp;
+    const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // pooled pixel (b, py, px): all COUT channels
+    const long long total = (long long)p.B * p.Hp * p.Hp;
     if (o >= total) return;                                        // whole wave
-    const int px = (int)(o % p.Hp), py = (int)((o / p.Hp) % p.Hp), co = (int)((o / ((long long)p.Hp * p.Hp)) % p.Cout);
-    const int bb = (int)(o / ((long long)p.Hp * p.Hp * p.Cout));
+    const int px = (int)(o % p.Hp), py = (int)((o / p.Hp) % p.Hp), bb = (int)(o / ((long long)p.Hp * p.Hp));
     const int kk = p.k * p.k, nprod = p.Cin * kk;
-    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+    float acc[COUT][4];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) { acc[co][0] = 0.f; acc[co][1] = 0.f; acc[co][2] = 0.f; acc[co][3] = 0.f; }
     const float* base = p.in + bb * p.sb;
-    for (int i = lane; i < nprod; i += 64) {
+    for (int i = lane; i < nprod; i += 64) {                       // the four conv outputs under one pooling window share w
         const int ci = i / kk, r = i - ci * kk, ky = r / p.k, kx = r - ky * p.k;
-        const float wv = p.w[(size_t)co * nprod + i];
         const float* q = base + ci * p.sc + (2 * py + ky) * p.sy + (2 * px + kx) * p.sx;
-        a00 += wv * q[0]; a01 += wv * q[p.sx]; a10 += wv * q[p.sy]; a11 += wv * q[p.sy + p.sx];
+        const float v00 = q[0], v01 = q[p.sx], v10 = q[p.sy], v11 = q[p.sy + p.sx];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float wv = p.w[(size_t)co * nprod + i];
+            acc[co][0] += wv * v00; acc[co][1] += wv * v01; acc[co][2] += wv * v10; acc[co][3] += wv * v11;
+        }
     }
-    a00 = wave_sum(a00); a01 = wave_sum(a01); a10 = wave_sum(a10); a11 = wave_sum(a11);
-    if (lane == 0) p.out[o] = fmaxf(fmaxf(fmaxf(a00, a01), fmaxf(a10, a11)) + p.bias[co], 0.f);   // max commutes with the shared bias
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        const float a = wave_sum(acc[co][0]), b = wave_sum(acc[co][1]), c = wave_sum(acc[co][2]), d = wave_sum(acc[co][3]);
+        if (lane == 0)                                             // max commutes with the shared bias
+            p.out[(((size_t)bb * COUT + co) * p.Hp + py) * p.Hp + px] = fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)) + p.bias[co], 0.f);
+    }
 }
 
 // fc_loc: theta = W2 relu(W1 xs + b1) + b2 (stn.py:32-36,46-48).  One workgroup per face.

@@ -808,7 +808,7 @@ static void add_stn(hd_ctx* c, std::vector<Op>& prog, const std::string& name, c
         q.w = w0; q.bias = b0; q.out = loc1; q.B = B; q.Cin = C; q.Hin = H; q.k = k0; q.Cout = 8; q.Hp = H1p;
         const long long total = (long long)B * 8 * H1p * H1p;
         prog.push_back({name + ".localization.0", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(stn_conv_pool_relu_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, q);
+                            hipLaunchKernelGGL(stn_conv_pool_relu_kernel<8>, dim3((unsigned)((total / 8 + 3) / 4)), dim3(256), 0, s, q);
                             return hipGetLastError();
                         }});
         prog.back().out = loc1; prog.back().out_elems = (size_t)total;
@@ -819,7 +819,7 @@ static void add_stn(hd_ctx* c, std::vector<Op>& prog, const std::string& name, c
         q.w = w3; q.bias = b3; q.out = loc2; q.B = B; q.Cin = 8; q.Hin = H1p; q.k = k1; q.Cout = 10; q.Hp = H2p;
         const long long total = (long long)B * 10 * H2p * H2p;
         prog.push_back({name + ".localization.3", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(stn_conv_pool_relu_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, q);
+                            hipLaunchKernelGGL(stn_conv_pool_relu_kernel<10>, dim3((unsigned)((total / 10 + 3) / 4)), dim3(256), 0, s, q);
                             return hipGetLastError();
                         }});
         prog.back().out = loc2; prog.back().out_elems = (size_t)total;

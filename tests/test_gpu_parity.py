@@ -296,7 +296,7 @@ def test_checkpoint_ingest(gpu, weights16, model2, inputs2, tmp_path):
         m3.to("cuda:0")                                             # fpg.convs.* have no source yet: state dict incomplete
 
 
-def test_coarse_restoration_against_reference_golden(gpu):
+def test_coarse_restoration_against_reference_golden(gpu, model2, inputs2):
     """`CoarseRestoration` (32 NAF blocks + 9 STNs, models/cr/model.py:33-88) through the library:
     output vs the reference's own output (fp32 golden) and vs the bf16-emulating oracle; a second batch size."""
     from hifidiff_amd import synth
@@ -317,3 +317,10 @@ def test_coarse_restoration_against_reference_golden(gpu):
     assert psnr(one, out[:1], data_range=1.0) >= 50.0
     with pytest.raises(RuntimeError):
         m(x[:, :, :64].cuda())                                                     # input must be 128x128
+    # the pipeline order of test_refiner.py:77-91: cr_face = cr_module(ln_face) feeds the refiner's sampling loop
+    from hifidiff_amd import sampling, schedulers
+    xT, crl, _ = [t.cuda() for t in inputs2]
+    sch = schedulers.DDIMScheduler(clip_sample_range=3.0)
+    sch.set_timesteps(50); sch.timesteps = sch.timesteps[:5]
+    lat = sampling.sample(model2, xT, m(x.cuda()), crl, sch)
+    assert bool(torch.isfinite(lat).all()) and float((lat - xT).abs().mean()) > 1e-3
