@@ -415,6 +415,8 @@ hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
 
 // conv1 with the depthwise 3x3 + SimpleGate + pool fused: workgroup = whole faces (BM = max(32, hw) rows)
 hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
+    // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle)
+    if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw == 64) return launch_skinny_auto<2, 1, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw == 256) return launch_skinny_auto<8, 1, true, LdF32LN, EpDwGate>(p, s);
