@@ -418,6 +418,8 @@ hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
     // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle)
     if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate>(p, s);
+    static const bool big64 = getenv("HD_NO_DW64_WM8") == nullptr;      // 256-row tiles (4 faces of 8x8) when 64-row tiles would put >= 4 workgroups on a CU
+    if (p.hw == 64 && big64 && p.M % 256 == 0 && (p.M / 64) * (p.N / 64) >= 1024) return launch_skinny_auto<8, 1, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw == 64) return launch_skinny_auto<2, 1, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw == 256) return launch_skinny_auto<8, 1, true, LdF32LN, EpDwGate>(p, s);
     return hipErrorInvalidValue;
@@ -458,7 +460,8 @@ int choose_mode(const GemmP& p, bool pair) {
     if (force >= 0) return force;
     const int nb256 = (ncols + (pair ? 127 : 255)) / (pair ? 128 : 256);
     if (p.Kp <= 256 && nb256 <= 2 && ((p.M + 31) / 32) * nb256 >= 512) return 4;   // levels 0/1 at full batch
-    if (p.Kp >= 1024 && p.M >= 2048) {                      // long-K gathers (HCA 3x3 at levels 0/1): chunks stay in flight per wave
+    static const int wm_mink = getenv("HD_WM_MINK") ? atoi(getenv("HD_WM_MINK")) : 512;
+    if (p.Kp >= wm_mink && p.M >= 2048) {                   // long-K gathers (HCA 3x3 at levels 0/1): chunks stay in flight per wave
         if (((p.M + 255) / 256) * nb32 >= 256) return 6;
         if (((p.M + 127) / 128) * nb32 >= 192) return 5;
     }
