@@ -574,7 +574,7 @@ struct EpDwGate1 {
     static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) {
         // fold: g = (A1 + wa * acc1) * (A2 + wb * acc2) with A = b2 + w * b1
         const int C2 = p.N >> 1;
-        const float wa = p.dw_w[(size_t)col * 9 + 4], wb = p.dw_w[(size_t)(col + C2) * 9 + 4];
+        const float wa = p.dw_w[(size_t)4 * p.N + col], wb = p.dw_w[(size_t)4 * p.N + col + C2];      // tap-major copy
         ColC c; c.bias = p.dw_b[col] + wa * p.bias[col]; c.bias2 = p.dw_b[col + C2] + wb * p.bias[col + C2];
         c.rscale = wa; c.rscale2 = wb;
         return c;
@@ -1045,6 +1045,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         LD::fetch(p, st[u], ((chunk) < c_end) ? (chunk) * BK : p.Kp, kq, aq[slot][u]);
 #pragma unroll
     for (int d = 0; d < D; ++d) { HD_SK_FETCH_A(d, c0 + d); }
+    // fused depthwise epilogue: its per-channel weights (tap-major copy: coalesced) are requested now, not after the
+    // K loop (a dependent global round trip inside the epilogue otherwise)
+    // (only in the 8-wave shapes: in the 4-wave shapes, two workgroups per CU, the extra live registers cost more)
+    constexpr bool kEarlyDw = EP::kTile && C::THREADS >= 512;
+    float dw_wa[9], dw_wb[9], dw_ba = 0.f, dw_bb = 0.f, dw_b1a = 0.f, dw_b1b = 0.f;
+    auto load_dw = [&]() {
+        const int ncols_e = p.N >> 1, col_e = tile[0] * 32 + (tid & 31);
+        const bool cok = col_e < ncols_e;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { dw_wa[t] = cok ? p.dw_w[(size_t)t * p.N + col_e] : 0.f; dw_wb[t] = cok ? p.dw_w[(size_t)t * p.N + col_e + ncols_e] : 0.f; }
+        if (cok) { dw_ba = p.dw_b[col_e]; dw_bb = p.dw_b[col_e + ncols_e]; dw_b1a = p.bias[col_e]; dw_b1b = p.bias[col_e + ncols_e]; }
+    };
+    if constexpr (kEarlyDw) load_dw();
     u32x4_t pf_sink = {0u, 0u, 0u, 0u};
     prefetch_issue(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y), tid, C::THREADS, pf_sink);
     HD_STAMP(6);
@@ -1114,10 +1127,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         // ================= conv1 bias -> depthwise 3x3 -> SimpleGate -> G, pooled =================
         static_assert(TNT == 2, "EpDwGate needs a PAIR tile");
         const int C2 = p.N >> 1;
+        if constexpr (!kEarlyDw) load_dw();
         // (1) sum the K-split partials in wave order, add conv1's bias, keep T1 in slice 0
         //     (rows beyond M hold zeros from the masked A loads; their outputs are never stored)
         {
-            const float bias_a = col < ncols ? p.bias[col] : 0.f, bias_b = col < ncols ? p.bias[col + C2] : 0.f;
+            const float bias_a = dw_b1a, bias_b = dw_b1b;
             for (int e = tid; e < C::BM * 32; e += C::THREADS) {
                 float va = bias_a, vb = bias_b;
 #pragma unroll
@@ -1132,15 +1146,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         float* rs = reinterpret_cast<float*>(smem + C::GT_OFF);          // [BM / S][32] row sums
         const int j = tid & 31;
         const int S = p.side, ls = 31 - __builtin_clz(S), HW = p.hw;     // S in {1,2,4,8,16}
-        float wa[9], wb[9], ba = 0.f, bb = 0.f;
-        if (col < ncols) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) { wa[t] = p.dw_w[(size_t)col * 9 + t]; wb[t] = p.dw_w[(size_t)(col + C2) * 9 + t]; }
-            ba = p.dw_b[col]; bb = p.dw_b[col + C2];
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) { wa[t] = 0.f; wb[t] = 0.f; }
-        }
+        const float (&wa)[9] = dw_wa; const float (&wb)[9] = dw_wb;
+        const float ba = dw_ba, bb = dw_bb;
         const float* t1a = red + j;
         const float* t1b = red + C::BM * 32 + j;
         const int nrows_img = C::BM >> ls;                               // image rows in the tile

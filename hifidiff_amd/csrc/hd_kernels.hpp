@@ -55,6 +55,14 @@ __global__ void pack_weight_kernel(const PackP p) {
     }
 }
 
+// depthwise weights [2C][9] -> tap-major [9][2C]: the fused conv1 epilogue reads them with one coalesced load per tap
+__global__ void dw_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT, int n2c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2c * 9) return;
+    const int ch = i / 9, t = i - ch * 9;
+    wT[(size_t)t * n2c + ch] = w[i];
+}
+
 // ----------------------------------------------------------------------------------- intro / ending
 // intro: Conv2d(4,128,3,pad 1) on the NCHW latent -> channels-last fp32 + bf16 copy + LayerNorm partial
 // (models/denoiser/model.py:159-167,235).  fp32 FMA (K = 36 is too small for MFMA).  One wave per run of 16

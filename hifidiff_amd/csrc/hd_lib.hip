@@ -46,6 +46,7 @@ struct BlockW {
     int C = 0, film_off = -1;
     PackedW conv1, conv3, sca, conv4, conv5;
     const float *dw_w = nullptr, *dw_b = nullptr, *beta = nullptr, *gamma = nullptr;
+    const float* dw_wT = nullptr;             // conv2.weight tap-major [9][2C] (fused conv1 epilogue)
 };
 
 struct HcaW {
@@ -530,7 +531,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         GemmP p = base_gemm(bw.conv1, M);
         p.A = lv.Xb; p.lda = C; film_fields(p, 0);
         p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
-        p.out = lv.G; p.ldo = C; p.dw_w = bw.dw_w; p.dw_b = bw.dw_b; p.pooled = lv.pooled; p.pooled16 = lv.pooled16; p.side = lv.H;
+        p.out = lv.G; p.ldo = C; p.dw_w = bw.dw_wT; p.dw_b = bw.dw_b; p.pooled = lv.pooled; p.pooled16 = lv.pooled16; p.side = lv.H;
         add_gemm(c, prog, bw.name + ".conv2_gate_pool", p, LK_LN, EK_DWGATE);
     } else {
         {   // LN1 + FiLM -> conv1 (+bias) -> T1
@@ -744,6 +745,17 @@ int run_ops(hd_ctx* c, std::vector<Op>& prog, hipStream_t s, int limit = -1) {
 // models/cr/model.py:73-88: intro -> 4 x [NAF blocks, STN, down] (stage outputs are the skips) -> [8 NAF, STN]
 // -> 4 x [(+ skip), NAF blocks, STN, up] -> outro.  Stage s works on level buffers of its own geometry
 // (C = 32 << level, side 128 >> level); NAF blocks, down- and up-convs are the refiner path's launches.
+// conv2.weight [2C][1][3][3] -> tap-major device copy for the fused conv1 epilogue
+static int make_dw_layout(hd_ctx* c, BlockW& bw) {
+    float* t = nullptr;
+    int rc = dev_alloc(c, &t, (size_t)2 * bw.C * 9);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dw_weight_layout_kernel, dim3((2 * bw.C * 9 + 255) / 256), dim3(256), 0, 0, bw.dw_w, t, 2 * bw.C);
+    HIPCHECK(c, hipGetLastError());
+    bw.dw_wT = t;
+    return HD_OK;
+}
+
 static int load_naf_block(hd_ctx* c, const std::string& p, int C, BlockW& bw) {
     bw.name = p; bw.C = C;
     int r = 0;
@@ -753,7 +765,7 @@ static int load_naf_block(hd_ctx* c, const std::string& p, int C, BlockW& bw) {
     if (r) return r;
     bw.dw_w = find_raw(c, p + ".conv2.weight")->dev; bw.dw_b = find_raw(c, p + ".conv2.bias")->dev;
     bw.beta = find_raw(c, p + ".beta")->dev; bw.gamma = find_raw(c, p + ".gamma")->dev;
-    return HD_OK;
+    return make_dw_layout(c, bw);
 }
 
 static int finalize_cr(hd_ctx* c) {
@@ -1383,8 +1395,7 @@ int hd_finalize_weights(hd_ctx* c) {
         if (r) return r;
         bw.dw_w = find_raw(c, p + ".conv2.weight")->dev; bw.dw_b = find_raw(c, p + ".conv2.bias")->dev;
         bw.beta = find_raw(c, p + ".beta")->dev; bw.gamma = find_raw(c, p + ".gamma")->dev;
-        c->weight_bytes_per_step += 0;   // accounted below for denoiser blocks only
-        return HD_OK;
+        return make_dw_layout(c, bw);
     };
     const int enc[4] = {2, 2, 4, 8};
     std::vector<std::pair<std::string, int>> order;

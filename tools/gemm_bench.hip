@@ -193,6 +193,13 @@ int main(int argc, char** argv) {
           const int nwg = ((M + 32 * MT * WM - 1) / (32 * MT * WM)) * (((PAIR) ? N / 2 : N) / 32);       \
           report_stamps(stamps, nwg < 8192 ? nwg : 8192); }                                              \
     }
+    if (M <= 1024 && K % 512 == 0) {        // deep-level fused conv1 (LN -> conv1 -> depthwise -> gate -> pool), faces of 2x2 / 4x4
+        float* pooled; CK(hipMalloc(&pooled, (size_t)M * N * 4));
+        float* dww; CK(hipMalloc(&dww, (size_t)N * 9 * 4)); hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, dww, (size_t)N * 9, 0.3f);
+        RUN_SKW("skinny W8 LN dwgate hw4 (L3 conv1 fused)", 1, 8, 1, true, 2, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = 4, p.side = 2))
+        RUN_SKW("skinny W8 LN dwgate hw16 (L2 conv1 fused)", 1, 8, 1, true, 2, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = 16, p.side = 4))
+        RUN_SKW("skinny W8 LN gate (no dw)", 1, 8, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+    }
     if (M >= 2048 && N >= 256) {
         float* pooled; CK(hipMalloc(&pooled, (size_t)(M / 16) * N * 4));
         float* dww; CK(hipMalloc(&dww, (size_t)N * 9 * 4)); hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, dww, (size_t)N * 9, 0.3f);
