@@ -929,21 +929,33 @@ __device__ __forceinline__ float dw_gate_row(const float* t1a, const float* t1b,
     return rsum;
 }
 
+// What the element-wise epilogue reads from global memory (per-column constants, residual / gate operands): requested
+// before the K loop so that the epilogue does not start with a dependent round trip.
+template <class C> struct SkinnyPre { static constexpr int NIT = (C::BM * 32 + C::THREADS - 1) / C::THREADS; ColC cc; float pre[NIT]; };
 template <bool FULL, class C, class EP>
-__device__ __forceinline__ void skinny_rows_epilogue(const GemmP& p, const float* red, int row0, int col, int ncols, int tile_idx, int tid) {
-    constexpr int NIT = (C::BM * 32 + C::THREADS - 1) / C::THREADS, TNT = C::TNT, WK = C::WK;
-    constexpr int TILE_F = C::BM * 32 * TNT;
+__device__ __forceinline__ void skinny_rows_pre(const GemmP& p, int row0, int col, int ncols, int tid, SkinnyPre<C>& sp) {
+    constexpr int NIT = SkinnyPre<C>::NIT;
     constexpr bool EVEN = (C::BM * 32) % C::THREADS == 0;
     const bool cv = FULL || col < ncols;
-    const ColC cc = EP::col_init(p, cv ? col : 0);
-    float pre[NIT], v[NIT];
+    sp.cc = EP::col_init(p, cv ? col : 0);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = it * C::THREADS + tid;
         const int row = row0 + (e >> 5);
         const bool ok = (EVEN || e < C::BM * 32) && (FULL || (row < p.M && cv));
-        pre[it] = ok ? EP::pre(p, row, col) : 0.f;
+        sp.pre[it] = ok ? EP::pre(p, row, col) : 0.f;
     }
+}
+template <bool FULL, class C, class EP>
+__device__ __forceinline__ void skinny_rows_epilogue(const GemmP& p, const float* red, int row0, int col, int ncols, int tile_idx, int tid,
+                                                     const SkinnyPre<C>& sp) {
+    constexpr int NIT = (C::BM * 32 + C::THREADS - 1) / C::THREADS, TNT = C::TNT, WK = C::WK;
+    constexpr int TILE_F = C::BM * 32 * TNT;
+    constexpr bool EVEN = (C::BM * 32) % C::THREADS == 0;
+    const bool cv = FULL || col < ncols;
+    const ColC cc = sp.cc;
+    const float (&pre)[NIT] = sp.pre;
+    float v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = it * C::THREADS + tid;
@@ -1058,6 +1070,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         if (cok) { dw_ba = p.dw_b[col_e]; dw_bb = p.dw_b[col_e + ncols_e]; dw_b1a = p.bias[col_e]; dw_b1b = p.bias[col_e + ncols_e]; }
     };
     if constexpr (kEarlyDw) load_dw();
+    // element-wise epilogues: same idea for their residual / gate operands and per-column constants (8-wave shapes)
+    constexpr bool kEarlyPre = !EP::kTile && !ep_is_sca_tile<EP>::value && C::THREADS >= 512;
+    SkinnyPre<C> spre;
+    if constexpr (kEarlyPre) {
+        const int ncols_e = (TNT == 2) ? (p.N >> 1) : p.N, col_e = tile[0] * 32 + (tid & 31);
+        const bool full_e = (row0 + C::BM <= p.M) && (tile[0] * 32 + 32 <= ncols_e);
+        if (full_e) skinny_rows_pre<true, C, EP>(p, row0, col_e, ncols_e, tid, spre);
+        else skinny_rows_pre<false, C, EP>(p, row0, col_e, ncols_e, tid, spre);
+    }
     u32x4_t pf_sink = {0u, 0u, 0u, 0u};
     prefetch_issue(p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y), tid, C::THREADS, pf_sink);
     HD_STAMP(6);
@@ -1227,8 +1248,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     } else {
         // ================= element-wise epilogue, 32 lanes = one row of the tile =================
         const bool full = (row0 + C::BM <= p.M) && (tile[0] * 32 + 32 <= ncols);      // workgroup-uniform
-        if (full) skinny_rows_epilogue<true, C, EP>(p, red, row0, col, ncols, tile[0], tid);
-        else skinny_rows_epilogue<false, C, EP>(p, red, row0, col, ncols, tile[0], tid);
+        if constexpr (!kEarlyPre) {
+            if (full) skinny_rows_pre<true, C, EP>(p, row0, col, ncols, tid, spre);
+            else skinny_rows_pre<false, C, EP>(p, row0, col, ncols, tid, spre);
+        }
+        if (full) skinny_rows_epilogue<true, C, EP>(p, red, row0, col, ncols, tile[0], tid, spre);
+        else skinny_rows_epilogue<false, C, EP>(p, red, row0, col, ncols, tile[0], tid, spre);
     }
     if (p.pf_base) prefetch_drain(pf_sink);
     HD_STAMP(5);
