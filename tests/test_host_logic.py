@@ -108,3 +108,16 @@ def test_two_rank_shard_and_gather_gloo(tmp_path, n_faces):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_cr_manifest_and_synthetic_weights():
+    """CoarseRestoration manifest (checked key-for-key against the reference in oracle/make_golden.py's container run):
+    664 tensors, nine STN heads whose synthetic last Linear leans to the identity transform."""
+    from hifidiff_amd import arch, synth
+    man = arch.cr_manifest()
+    assert len(man) == 664 and list(man)[0] == "intro.weight" and list(man)[-1] == "decoders.3.sampling.0.weight"
+    assert man["encoders.0.stn.fc_loc.0.weight"][0] == (85, 7290) and man["middle_blocks.stn.localization.0.weight"][0] == (8, 512, 3, 3)
+    assert [s[1:3] for s in arch.cr_stages()] == [(32, 128), (64, 64), (128, 32), (256, 16), (512, 8), (512, 8), (256, 16), (128, 32), (64, 64)]
+    sd = synth.cr_state_dict()
+    b = sd["decoders.2.stn.fc_loc.2.bias"]
+    assert abs(float(b[0]) - 1.0) < 0.1 and abs(float(b[4]) - 1.0) < 0.1 and float(b[[1, 2, 3, 5]].abs().max()) < 0.1
