@@ -170,9 +170,12 @@ def main():
             "value": round(value, 3), "unit": "faces/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch %d per GPU, latent %d (%d->%d px), %d-step %s "
-                                   "(fixed_small variance, clip 3.0), conditioning prologue included, device Philox noise"
-                                   % (B, L, L, L * 8, n_diff, a.kind.upper()),
+            "config": {"workload": "%sbatch %d per GPU, latent %d (%d->%d px), %d-step %s "
+                                   "(clip 3.0%s), conditioning prologue included%s"
+                                   % ("BASELINE configs[1]: " if (L == 16 and a.kind == "ddpm" and n_diff == 1000 and B == 64) else
+                                      "BASELINE configs[3]: " if (L == 32 and a.kind == "ddim" and n_diff == 250 and B == 64) else "",
+                                      B, L, L, L * 8, n_diff, a.kind.upper(), ", fixed_small variance" if a.kind == "ddpm" else ", eta 0",
+                                      ", device Philox noise" if a.kind == "ddpm" else ""),
                        "faces_per_gpu": B, "latent_res": L, "diffusion_steps": n_diff, "sampler": a.kind,
                        "parallelism": "batch-sharded x%d, no in-loop collective" % world,
                        "concurrent_chains": Lh.hd_num_chains(model.engine.ctx),
