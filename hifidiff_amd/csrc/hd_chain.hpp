@@ -31,7 +31,15 @@ struct ChainP {
     float2* stats_out;                // [M][C/32] (mean, M2) partials of x', or NULL
     unsigned short* outg16;           // HCA-gated copy (x' + add) * (1 + w_c + w_s), or NULL
     const float *gate_c, *gate_s, *add_src;
+#ifdef HD_STAMPS
+    unsigned long long* stamps;       // diagnostic build (tools/gemm_bench): [workgroup][8] s_memrealtime ticks
+#endif
 };
+#ifdef HD_STAMPS
+#define HD_CSTAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HD_CSTAMP(i) do { } while (0)
+#endif
 
 // MT: 32-row MFMA tiles per wave (BM = 32*MT rows per workgroup).  A workgroup re-reads all 5*C*C weights of the
 // block; MT = 2 halves that traffic at level 0 but leaves a single 4-wave workgroup per CU, whose barrier-separated
@@ -91,8 +99,10 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
     const int col = tile * 32 + (lane & 31);
     const bool full = row0 + K::BM <= p.M;
 
+    HD_CSTAMP(0);
     uint4 bw[K::KS], bw2[K::KS];
-    chain_load_b<C>(p.Wsca, tile, lane, bw);                       // SCA weights first
+    chain_load_b<C>(p.Wsca, tile, lane, bw);                       // SCA weights first,
+    chain_load_b<C>(p.W3, tile, lane, bw2);                        // conv3's right behind them (second register set)
     // ---- FiLM gain/bias of norm2 for this face/step into LDS ----
     {
         const int step = p.step_ptr ? *p.step_ptr : 0;
@@ -120,7 +130,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ks]), __builtin_bit_cast(bf16x8_t, bw[ks]), acc, 0, 0, 0);
         if (lane < 32) s_vec[col] = acc[0] + p.bsca[col];          // C/D row 0 = reg 0 of lanes 0..31
     }
-    chain_load_b<C>(p.W3, tile, lane, bw);                         // conv3 weights fly during the staging below
+    chain_load_b<C>(p.W4, tile, lane, bw);                         // conv4's first gate half flies during the staging and conv3
     // residual x for this wave's tile (needed by the conv3 epilogue): request it now as well
     float xr[MT][16];
 #pragma unroll
@@ -132,6 +142,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
         }
     __syncthreads();
 
+    HD_CSTAMP(1);                                                  // SCA done
     // ---- A1 = bf16(G * s): 32 rows x C, whole 128-byte lines ----
     {
         char* sA = smem + K::A1_OFF;
@@ -151,12 +162,12 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
     }
     __syncthreads();
 
+    HD_CSTAMP(2);                                                  // A1 staged
     // ---- conv3 -> y = x + beta * (acc + b3) into LDS ----
     {
         f32x16_t acc[MT];
-        chain_mma<C, MT>(smem + K::A1_OFF, bw, lane, acc);
-        chain_load_b<C>(p.W4, tile, lane, bw);                     // conv4 weights (both gate halves) for later
-        chain_load_b<C>(p.W4, tile + K::NT, lane, bw2);
+        chain_mma<C, MT>(smem + K::A1_OFF, bw2, lane, acc);
+        chain_load_b<C>(p.W4, tile + K::NT, lane, bw2);            // second gate half, now that conv3 has consumed its registers
         const float bb = p.b3[col], be = p.beta[col];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -168,26 +179,30 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
     }
     __syncthreads();
 
+    HD_CSTAMP(3);                                                  // conv3 done
     // ---- LayerNorm + FiLM on y (statistics fp32 two-pass; the normalised value is the bf16 copy of y, as in
     //      the unfused path) -> A2 ----
     {
         char* sA = smem + K::A2_OFF;
-        constexpr int PER = C / 64;                                  // values per lane per row
+        // 16 lanes per row (one DPP row: row16_sum leaves the sum in all 16 lanes), four rows per wave pass
+        constexpr int PER = C / 16;                                  // values per lane per row
         constexpr int RPW = K::BM / K::WAVES;                        // rows per wave
-        for (int rl = wave * RPW; rl < wave * RPW + RPW; ++rl) {
+        static_assert(RPW % 4 == 0, "rows per wave");
+        const int l16 = lane & 15;
+        for (int rl = wave * RPW + (lane >> 4); rl < wave * RPW + RPW; rl += 4) {
             float v[PER];
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) { v[i] = yt[rl * K::YROW + lane + 64 * i]; sum += v[i]; }
-            const float mean = wave_sum(sum) * (1.0f / C);
+            for (int i = 0; i < PER; ++i) { v[i] = yt[rl * K::YROW + l16 + 16 * i]; sum += v[i]; }
+            const float mean = row16_sum(sum) * (1.0f / C);
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q += d * d; }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + p.ln_eps);
+            const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / C) + p.ln_eps);
             const float nmr = -mean * rstd;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const int k = lane + 64 * i;
+                const int k = l16 + 16 * i;
                 const float yq = bf16_bits_to_f32(f32_to_bf16_bits(v[i]));
                 const float a = fmaf(fmaf(yq, rstd, nmr), gb[k], gb[C + k]);
                 *reinterpret_cast<unsigned short*>(sA + rl * K::AROW + k * 2) = f32_to_bf16_bits(a);
@@ -196,6 +211,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
     }
     __syncthreads();
 
+    HD_CSTAMP(4);                                                  // LN done
     // ---- conv4 (tile j and tile j + C/32) -> SimpleGate -> A3 (reuses the A1 region) ----
     {
         f32x16_t acc1[MT], acc2[MT];
@@ -214,6 +230,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
     }
     __syncthreads();
 
+    HD_CSTAMP(5);                                                  // conv4 + gate done
     // ---- conv5 -> x' = y + gamma * (acc + b5): fp32, bf16 copy, LayerNorm partials, optional HCA-gated copy ----
     {
         f32x16_t accs[MT];
@@ -262,6 +279,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
             }
         }
     }
+    HD_CSTAMP(6);
 }
 
 template <int C, int MT>

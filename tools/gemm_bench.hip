@@ -8,6 +8,7 @@
 #include <vector>
 #define HD_STAMPS 1
 #include "../hifidiff_amd/csrc/hd_gemm.hpp"
+#include "../hifidiff_amd/csrc/hd_chain.hpp"
 #include <algorithm>
 using namespace hd;
 
@@ -199,6 +200,36 @@ int main(int argc, char** argv) {
         RUN_SKW("skinny W8 LN dwgate hw4 (L3 conv1 fused)", 1, 8, 1, true, 2, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = 4, p.side = 2))
         RUN_SKW("skinny W8 LN dwgate hw16 (L2 conv1 fused)", 1, 8, 1, true, 2, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = 16, p.side = 4))
         RUN_SKW("skinny W8 LN gate (no dw)", 1, 8, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+    }
+    if (getenv("CHAIN") && (K == 128 || K == 256) && K == N) {
+        // ---- the row-local NAF tail as one kernel (hd_chain.hpp): phase stamps ----
+        const int C = K, hw = (C == 128) ? 256 : 64;
+        ChainP q{};
+        float *pooled, *X, *Xo, *bv; unsigned short *G, *Xb; float2* so;
+        CK(hipMalloc(&pooled, (size_t)(M / hw) * C * 4)); CK(hipMalloc(&X, (size_t)M * C * 4)); CK(hipMalloc(&Xo, (size_t)M * C * 4));
+        CK(hipMalloc(&bv, (size_t)4 * C * 4)); CK(hipMalloc(&G, (size_t)M * C * 2)); CK(hipMalloc(&Xb, (size_t)M * C * 2)); CK(hipMalloc(&so, (size_t)M * (C / 32) * 8));
+        hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, pooled, (size_t)(M / hw) * C, 0.5f);
+        hipLaunchKernelGGL(fillf_kernel, dim3(256), dim3(256), 0, s, X, (size_t)M * C, 1.0f);
+        hipLaunchKernelGGL(fillf_kernel, dim3(64), dim3(256), 0, s, bv, (size_t)4 * C, 0.1f);
+        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, (unsigned*)G, (size_t)M * C / 2, 77u);
+        q.M = M; q.hw = hw; q.G = G; q.pooled = pooled; q.X = X;
+        q.Wsca = b.W[0]; q.W3 = b.W[1 % nrot]; q.W4 = b.W[2 % nrot]; q.W5 = b.W[3 % nrot];
+        q.bsca = bv; q.b3 = bv; q.b4 = bv; q.b5 = bv; q.beta = bv; q.gamma = bv;
+        q.film = b.film; q.film_gain_off = 0; q.film_bias_off = C; q.ln_eps = 1e-6f;
+        q.Xout = Xo; q.Xout16 = Xb; q.stats_out = so; q.stamps = nullptr;
+        auto run = [&](const ChainP& qq) { return C == 128 ? launch_chain<128, 1>(qq, s) : launch_chain<256, 1>(qq, s); };
+        float us = time_it([&](int) { (void)run(q); }, iters, s);
+        CK(hipMemsetAsync(stamps, 0, 8192 * 64, s)); q.stamps = stamps; (void)run(q); CK(hipStreamSynchronize(s));
+        const int nwg = M / 32;
+        std::vector<unsigned long long> h((size_t)nwg * 8); CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        const char* nm[6] = {"sca", "stageA1", "conv3", "LN", "conv4", "conv5+epi"};
+        printf("chain C=%d M=%d: %.2f us;", C, M, us);
+        unsigned long long t0 = ~0ull, t6 = 0;
+        for (int w = 0; w < nwg; ++w) { t0 = std::min(t0, h[(size_t)w * 8]); t6 = std::max(t6, h[(size_t)w * 8 + 6]); }
+        printf(" span %.2f;", (double)(t6 - t0) * 0.01);
+        for (int i = 0; i < 6; ++i) { std::vector<double> d; for (int w = 0; w < nwg; ++w) d.push_back((double)(h[(size_t)w * 8 + i + 1] - h[(size_t)w * 8 + i]) * 0.01); std::sort(d.begin(), d.end()); printf(" %s %.2f/%.2f", nm[i], d[d.size() / 2], d.back()); }
+        { std::vector<double> d; for (int w = 0; w < nwg; ++w) d.push_back((double)(h[(size_t)w * 8] - t0) * 0.01); std::sort(d.begin(), d.end()); printf(" | start skew %.2f/%.2f\n", d[d.size() / 2], d.back()); }
+        return 0;
     }
     if (M >= 2048 && N >= 256) {
         float* pooled; CK(hipMalloc(&pooled, (size_t)(M / 16) * N * 4));
