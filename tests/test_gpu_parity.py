@@ -324,3 +324,25 @@ def test_coarse_restoration_against_reference_golden(gpu, model2, inputs2):
     sch.set_timesteps(50); sch.timesteps = sch.timesteps[:5]
     lat = sampling.sample(model2, xT, m(x.cuda()), crl, sch)
     assert bool(torch.isfinite(lat).all()) and float((lat - xT).abs().mean()) > 1e-3
+
+
+def test_graph_reuse_across_schedules(gpu, model2, inputs2):
+    """The captured step graph is reused across calls; a longer schedule re-allocates the FiLM table (and must
+    re-capture), a shorter one afterwards must give the first result again, bit for bit."""
+    from hifidiff_amd import sampling, schedulers
+    x, crl, crf = [t.cuda() for t in inputs2]
+
+    def run(n_total, n_run):
+        sch = schedulers.DDIMScheduler(clip_sample_range=3.0)
+        sch.set_timesteps(n_total)
+        sch.timesteps = sch.timesteps[:n_run]
+        return sampling.sample(model2, x, crf, crl, sch)
+    a = run(50, 6)
+    b = run(250, 40)                                   # more FiLM rows than before
+    c = run(50, 6)
+    assert torch.equal(a, c) and not torch.equal(a, b)
+    d = schedulers.DDPMScheduler(clip_sample_range=3.0)
+    d.timesteps = d.timesteps[:3]
+    e1 = sampling.sample(model2, x, crf, crl, d, seed=5)
+    e2 = sampling.sample(model2, x, crf, crl, d, seed=5)
+    assert torch.equal(e1, e2) and bool(torch.isfinite(e1).all())
