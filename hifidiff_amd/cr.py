@@ -101,6 +101,8 @@ class CoarseRestoration(nn.Module):
         B = x.shape[0]
         if tuple(x.shape) != (B, 3, 128, 128):
             raise RuntimeError("CoarseRestoration input must be (B,3,128,128), got %s" % (tuple(x.shape),))
+        if B == 0:
+            return torch.empty_like(x, dtype=torch.float32)
         if self._batch is not None and self._batch != B:      # a context's workspace is sized by its first batch
             self._upload()
         self._batch = B

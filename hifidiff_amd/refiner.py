@@ -303,6 +303,8 @@ class Denoiser(nn.Module):
     def forward(self, latents, timesteps):
         e = self._engine
         e.ensure(latents.device)
+        if latents.shape[0] == 0:
+            return UNet2DOutput(torch.empty_like(latents, dtype=torch.float32))
         e.prepare_unconditional(latents.shape[0])
         return UNet2DOutput(e.eps(latents, timesteps))
 
@@ -368,5 +370,7 @@ class FacialRefiner(nn.Module):
         e.cond_key = key
 
     def forward(self, latents, timesteps, cr_face, cr_latent):
+        if latents.shape[0] == 0:                          # empty batch: like the reference's convs, an empty result
+            return UNet2DOutput(torch.empty_like(latents, dtype=torch.float32))
         self.prepare(cr_face, cr_latent)
         return UNet2DOutput(self._engine.eps(latents, timesteps))

@@ -45,6 +45,8 @@ def sample(model, latents, cr_face, cr_latent, scheduler, noise=None, seed=0, pr
     For the unconditional `Denoiser` pass cr_face = cr_latent = None."""
     e = model.engine
     e.ensure(latents.device)
+    if latents.shape[0] == 0:                              # empty batch: nothing to sample
+        return latents.to(device=e.device, dtype=torch.float32).clone()
     if not e.conditional:
         if cr_face is not None or cr_latent is not None:
             raise RuntimeError("the unconditional Denoiser takes no cr_face / cr_latent")

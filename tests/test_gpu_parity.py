@@ -237,6 +237,11 @@ def test_error_behaviour(gpu, weights16, model2, inputs2):
     m2.to("cuda:0")
     with pytest.raises(RuntimeError):
         m2(x, 0, crf, crl)                                         # weights never loaded
+    # empty batch: an empty result, as the reference's convolutions would give
+    from hifidiff_amd import sampling, schedulers
+    assert tuple(model2(x[:0], 0, crf[:0], crl[:0]).sample.shape) == (0, 4, 16, 16)
+    sch = schedulers.DDIMScheduler(clip_sample_range=3.0); sch.set_timesteps(5)
+    assert tuple(sampling.sample(model2, x[:0], crf[:0], crl[:0], sch).shape) == (0, 4, 16, 16)
 
 
 def test_unconditional_denoiser_against_reference_golden(gpu, weights16):
