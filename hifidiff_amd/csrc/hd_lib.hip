@@ -471,7 +471,10 @@ int choose_mode(const GemmP& p, bool pair) {
         if (((p.M + 127) / 128) * nb64 >= 256) return 0;
         if (((p.M + 63) / 64) * nb64 >= 256) return 1;
     }
-    if (((p.M + 63) / 64) * nb32 >= 192) return 2;
+    // 64-row tiles halve the weight re-reads; with a short K (<= 512) and a grid that would only just fill the chip,
+    // 32-row tiles (twice the workgroups, two per CU) hide more latency (level 2: conv3/conv5 7.7 -> 6.3 us)
+    const int wg64 = ((p.M + 63) / 64) * nb32;
+    if (wg64 >= 192 && (p.Kp > 512 || wg64 >= 512)) return 2;
     return 3;
 }
 
