@@ -461,8 +461,10 @@ int choose_mode(const GemmP& p, bool pair) {
     if (force >= 0) return force;
     const int nb256 = (ncols + (pair ? 127 : 255)) / (pair ? 128 : 256);
     if (p.Kp <= 256 && nb256 <= 2 && ((p.M + 31) / 32) * nb256 >= 512) return 4;   // levels 0/1 at full batch
-    static const int wm_mink = getenv("HD_WM_MINK") ? atoi(getenv("HD_WM_MINK")) : 512;
-    if (p.Kp >= wm_mink && p.M >= 2048) {                   // long-K gathers (HCA 3x3 at levels 0/1): chunks stay in flight per wave
+    // many-row GEMMs: 128/256-row workgroups (waves stacked along M, each with its own K chunks in flight) once K is
+    // long (>= 1024), or from K = 512 when 64-row tiles would put four or more workgroups on a CU (latent 32)
+    const bool wm_ok = p.Kp >= 1024 || (p.Kp >= 512 && ((p.M + 63) / 64) * nb32 >= 1024);
+    if (wm_ok && p.M >= 2048) {
         if (((p.M + 255) / 256) * nb32 >= 256) return 6;
         if (((p.M + 127) / 128) * nb32 >= 192) return 5;
     }
