@@ -1070,6 +1070,20 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         if (cok) { dw_ba = p.dw_b[col_e]; dw_bb = p.dw_b[col_e + ncols_e]; dw_b1a = p.bias[col_e]; dw_b1b = p.bias[col_e + ncols_e]; }
     };
     if constexpr (kEarlyDw) load_dw();
+    // SCA tile epilogue: the G rows it rescales in place are requested now as well (first two 16-byte units per thread)
+    uint4 sca_g[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    if constexpr (ep_is_sca_tile<EP>::value) {
+        const int hw = p.scale_hw, units = C::BM * hw * 4;
+        if (hw > 0 && tile[0] * 32 + 32 <= p.N) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int u = tid + j * C::THREADS;
+                const int f = u / (hw * 4), rem = u - f * hw * 4, r = rem >> 2, q = rem & 3;
+                if (u < units && row0 + f < p.M)
+                    sca_g[j] = *reinterpret_cast<const uint4*>(p.scale_G + ((size_t)(row0 + f) * hw + r) * p.ldo + tile[0] * 32 + q * 8);
+            }
+        }
+    }
     // element-wise epilogues: same idea for their residual / gate operands and per-column constants (8-wave shapes)
     constexpr bool kEarlyPre = !EP::kTile && !ep_is_sca_tile<EP>::value && C::THREADS >= 512;
     SkinnyPre<C> spre;
@@ -1231,7 +1245,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
                     ok[j] = u < units && face < p.M;
                     gp[j] = p.scale_G + ((size_t)(ok[j] ? face : 0) * hw + r) * p.ldo + tile[0] * 32 + q * 8;
                     sp[j] = red + f * 32 + q * 8;
-                    g[j] = ok[j] ? *reinterpret_cast<const uint4*>(gp[j]) : make_uint4(0, 0, 0, 0);
+                    g[j] = (u0 == tid) ? sca_g[j]                     // first pass: fetched before the K loop
+                                       : (ok[j] ? *reinterpret_cast<const uint4*>(gp[j]) : make_uint4(0, 0, 0, 0));
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
