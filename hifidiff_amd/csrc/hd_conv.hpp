@@ -64,7 +64,9 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
     // weights first: independent of everything else.  Step n = tap * CPW + j reads k-step tap * SPT + ksl * CPW + j.
     uint4 bq[K::DEPTH];
     const uint4* Wl = p.W + ((size_t)tile * K::KSTEPS + ksl * K::CPW) * 64 + lane;
-#define HD_CONV_B(n) Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64]
+    // level 3 and deeper: 19+ MB of weights that only eight row groups share -> non-temporal stream (see gemm_skinny_kernel)
+#define HD_CONV_B(n) (K::C >= 1024 ? nt_load_u4(&Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64]) \
+                                   : Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64])
 #pragma unroll
     for (int d = 0; d < K::DEPTH; ++d) bq[d] = HD_CONV_B(d);
 
