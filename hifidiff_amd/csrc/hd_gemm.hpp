@@ -998,7 +998,7 @@ __device__ __forceinline__ void skinny_rows_epilogue(const GemmP& p, const float
     }
 }
 
-template <class C, class LD, class EP>
+template <class C, class LD, class EP, bool W_NT = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = C::MT, TNT = C::TNT, WK = C::WK, D = C::D, UN = C::UN;
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     // weight tiles that only a handful of row groups share are streamed with the non-temporal policy (they are not
     // needed again this step; measured: middle level -2.4 us per block, level 3 -1 us); tiles shared by many row
     // groups (level 2: 32) must stay in L2 and are loaded normally
-    const bool w_nt = p.w_nt != 0;
+    constexpr bool w_nt = W_NT;                                // compile-time: p.w_nt picks the instantiation (launch_skinny)
     HD_STAMP(0);
 
     f32x16_t acc[MT][TNT];
@@ -1316,18 +1316,20 @@ template <class C, class LD, class EP>
 inline hipError_t launch_skinny(const GemmP& p, hipStream_t s) {
     const int smem = C::GB_OFF + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0);
     if (smem > 160 * 1024 || (p.Kp / 64) % C::WK != 0) return hipErrorInvalidValue;
+    const bool nt = p.w_nt != 0;
     if (smem > 65536) {
-        static bool granted = false;
-        if (!granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static bool granted[2] = {false, false};
+        if (!granted[nt]) {
+            hipError_t e = nt ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                              : hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            granted = true;
+            granted[nt] = true;
         }
     }
     const int ncols = (C::TNT == 2) ? p.N / 2 : p.N;
     dim3 grid((p.M + C::BM - 1) / C::BM, (ncols + 31) / 32, 1);
-    hipLaunchKernelGGL((gemm_skinny_kernel<C, LD, EP>), grid, dim3(C::THREADS), smem, s, p);
+    if (nt) hipLaunchKernelGGL((gemm_skinny_kernel<C, LD, EP, true>), grid, dim3(C::THREADS), smem, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<C, LD, EP, false>), grid, dim3(C::THREADS), smem, s, p);
     return hipGetLastError();
 }
 

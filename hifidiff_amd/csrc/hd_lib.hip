@@ -493,7 +493,8 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
         const size_t a_bytes = (size_t)p.M * p.Kp * ((lk == LK_BF16 || lk == LK_BF16S || lk == LK_CONV_BF16 || lk == LK_LN) ? 2 : 4);
         p.xcd_tile_affine = ((size_t)p.N * p.Kp * 2 > a_bytes) ? 1 : 0;
         static const bool no_nt = getenv("HD_NO_NT") != nullptr;
-        p.w_nt = (!no_nt && p.xcd_tile_affine && p.M <= 256) ? 1 : 0;     // <= 8 row groups share a weight tile
+        static const int nt_maxm = getenv("HD_NT_MAXM") ? atoi(getenv("HD_NT_MAXM")) : 256;
+        p.w_nt = (!no_nt && p.xcd_tile_affine && p.M <= nt_maxm) ? 1 : 0;     // <= 8 row groups share a weight tile
     }
     const bool film = (lk == LK_LN);
     size_t out_rows = (size_t)p.M * (ek == EK_PIXSHUF ? p.shuffle_r * p.shuffle_r : 1);
