@@ -13,6 +13,9 @@
 //   compile-time constant of the unrolled loop); KS > 1: partial tiles are summed through LDS in slice order.
 #pragma once
 #include "hd_gemm.hpp"
+#ifndef HD_CONV_NT_MINC
+#define HD_CONV_NT_MINC 1024
+#endif
 
 namespace hd {
 
@@ -65,7 +68,7 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
     uint4 bq[K::DEPTH];
     const uint4* Wl = p.W + ((size_t)tile * K::KSTEPS + ksl * K::CPW) * 64 + lane;
     // level 3 and deeper: 19+ MB of weights that only eight row groups share -> non-temporal stream (see gemm_skinny_kernel)
-#define HD_CONV_B(n) (K::C >= 1024 ? nt_load_u4(&Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64]) \
+#define HD_CONV_B(n) (K::C >= HD_CONV_NT_MINC ? nt_load_u4(&Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64]) \
                                    : Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64])
 #pragma unroll
     for (int d = 0; d < K::DEPTH; ++d) bq[d] = HD_CONV_B(d);
