@@ -85,6 +85,24 @@ def gen_uncond(args):
 
 
 @torch.no_grad()
+def gen_l32_loop(args):
+    """BASELINE configs[3] in miniature: FacialRefiner(32) (32->256 px), the first 20 steps of the 250-step DDIM schedule
+    (eta 0, clip 3.0), one face: the reference network inside the restated scheduler."""
+    FacialRefiner = import_reference(args.ref)[0]
+    net = FacialRefiner(32).eval()
+    net.load_state_dict(synth.refiner_state_dict(32), strict=True)
+    x, crl, crf = synth.sample_inputs(1, 32)
+    sch = O.DDIMScheduler(clip_sample=True, clip_sample_range=3.0)
+    sch.set_timesteps(250)
+    lat = x.clone()
+    for t in sch.timesteps[:20]:
+        eps = net(lat, torch.full((1,), int(t)), crf, crl).sample
+        lat = sch.step(eps, int(t), lat).prev_sample
+    np.savez_compressed(os.path.join(args.out, "ddim250_first20_L32.npz"), final=lat.numpy())
+    print("wrote ddim250_first20_L32.npz", lat.shape, float(lat.abs().max()))
+
+
+@torch.no_grad()
 def gen_cr(args):
     """CoarseRestoration (models/cr/model.py:33-88) on two synthetic 128x128 faces: output, the nine STN thetas and
     the stage outputs.  The synthetic fc_loc.2 weights are scaled down so that theta stays near the identity the
@@ -126,6 +144,8 @@ def main():
         return gen_uncond(args)
     if args.only == "cr":
         return gen_cr(args)
+    if args.only == "l32loop":
+        return gen_l32_loop(args)
     FacialRefiner, CondBlock, PosEmb, HCA = import_reference(args.ref)
 
     t0 = time.time()

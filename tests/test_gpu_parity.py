@@ -186,6 +186,13 @@ def test_latent32_against_reference_golden(gpu):
     x, crl, crf = synth.sample_inputs(1, 32)
     eps = m(x.cuda(), torch.full((1,), 500), crf.cuda(), crl.cuda()).sample.cpu()
     assert rel_l2(eps, golden("refiner_eps_L32.npz")["eps_t500"]) <= 1e-2
+    # BASELINE configs[3] in miniature: the first 20 steps of the 250-step DDIM schedule, graph-replayed
+    from hifidiff_amd import sampling, schedulers
+    sch = schedulers.DDIMScheduler(clip_sample_range=3.0)
+    sch.set_timesteps(250)
+    sch.timesteps = sch.timesteps[:20]
+    lat = sampling.sample(m, x.cuda(), crf.cuda(), crl.cuda(), sch).cpu()
+    assert psnr(lat, golden("ddim250_first20_L32.npz")["final"]) >= 40.0
 
 
 def test_full_batch_properties(gpu, weights16):
