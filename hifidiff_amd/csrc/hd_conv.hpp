@@ -13,6 +13,9 @@
 //   compile-time constant of the unrolled loop); KS > 1: partial tiles are summed through LDS in slice order.
 #pragma once
 #include "hd_gemm.hpp"
+#ifndef HD_CONV_DEPTH
+#define HD_CONV_DEPTH 8
+#endif
 #ifndef HD_CONV_NT_MINC
 #define HD_CONV_NT_MINC 1024
 #endif
@@ -177,9 +180,9 @@ inline hipError_t launch_hca_conv(const ConvP& p, hipStream_t s) {
 }
 
 // Shapes of the refiner at latent 16: level l has C = 128 << l channels and faces of side 16 >> l.
-typedef ConvCfg<128, 16, 256, 2, 2> ConvL0;    // one face per workgroup: 4 row groups x 2 K-halves
-typedef ConvCfg<256, 8, 128, 2, 4> ConvL1;     // two faces: 2 row groups x 4 K-quarters
-typedef ConvCfg<512, 4, 64, 2, 8> ConvL2;      // four faces: 1 row group x 8 K-slices
+typedef ConvCfg<128, 16, 256, 2, 2, HD_CONV_DEPTH> ConvL0;    // one face per workgroup: 4 row groups x 2 K-halves
+typedef ConvCfg<256, 8, 128, 2, 4, HD_CONV_DEPTH> ConvL1;     // two faces: 2 row groups x 4 K-quarters
+typedef ConvCfg<512, 4, 64, 2, 8, HD_CONV_DEPTH> ConvL2;      // four faces: 1 row group x 8 K-slices
 typedef ConvCfg<1024, 2, 32, 1, 8, 16> ConvL3; // eight faces; 590 KB of weights per workgroup: deeper ring
 // latent 32: faces of side 32 >> l (level 0's 32x32 faces do not fit LDS and keep the gather form)
 typedef ConvCfg<256, 16, 256, 2, 2> ConvL1x32;
