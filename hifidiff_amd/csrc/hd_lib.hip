@@ -518,10 +518,11 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
     prog.push_back(op);
 }
 
-// One (Conditional)NAFBlock on level buffers (conditional_naf.py:108-136 / naf.py:105-126), six launches.
+// One (Conditional)NAFBlock on level buffers (conditional_naf.py:108-136 / naf.py:105-126): two launches
+// where the row-local chain kernel applies (C = 128 / 256), five with the fused conv1 epilogue, seven in the unfused form.
 // static_film: FPG blocks use the LayerNorm affine itself as the "FiLM" row (scale = shift = 0).
 // x_np/x_cnt: how the LayerNorm partials of the block input X were produced (C/32 x 32 by a GEMM
-// epilogue, 1 x C by intro / row_stats); on return they describe conv5's output.
+// epilogue, 1 x C by the intro conv or a skip-add); on return they describe conv5's output.
 struct GateOut { const float* gate_c = nullptr; const float* gate_s = nullptr; const float* add = nullptr; };
 void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Level& lv, const float* static_film, int* x_np,
                    int* x_cnt, const GateOut* gate = nullptr) {
@@ -1747,7 +1748,7 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
     c->film_face_stride = 0;
     c->film_from_cur = true;
     c->advance = 1;
-    for (auto& ch : c->chains)                          // step 0's row; sched_step stages row i+1 during step i
+    for (auto& ch : c->chains)                          // step 0's row; the ending launch of step i stages row i+1
         HIPCHECK(c, hipMemcpyAsync(ch.film_cur, c->film_table, (size_t)c->film_total * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!c->graphs_valid || c->graph_film != c->film_table || c->graph_B != c->B) {
         // One graph per chain: its launch program + its scheduler update.  Faces never interact, so the
