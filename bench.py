@@ -2,8 +2,13 @@
 """Headline benchmark: faces/sec, 16->128 px, 1000-step DDPM reverse diffusion, batch 64 per GPU
 (BASELINE.json configs[1]; SURVEY §8d "Config 2").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Without RANK/WORLD_SIZE in the environment and N > 1 the parent spawns N fresh worker processes (one per
+GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1) BEFORE it imports torch or makes any
+GPU call, relays rank 0's JSON line and exits non-zero if any worker fails.  This is the plain-command
+form of `accelerator.prepare(val_dataloader, model)` (reference test_refiner.py:173-174).
 
 One "step" = one complete reverse-diffusion pass over the rank's batch of synthetic faces: the
 once-per-batch conditioning prologue (FPG, ResNet-50 IDC, HCA gates, idc_conv), the FiLM table for all
@@ -29,31 +34,107 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
+
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def self_launch(n):
+    """Parent of a plain `python bench.py --gpus N` (N > 1): N child processes, one rank each.  Nothing here
+    touches the GPU (torch is not even imported yet): a process that has initialised HIP must never be the
+    one that starts or re-execs workers."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HD_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    codes = [p.wait() for p in procs]
+    if out0:
+        sys.stdout.write(out0.decode())
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
+    sys.exit(self_launch(_requested_gpus(sys.argv[1:])))
+
 import torch  # noqa: E402
 
 SURVEY_WEIGHT_BYTES = {16: 722.66e6, 32: 790.28e6}      # SURVEY §8d: effective params x 2 B
 SURVEY_FLOPS_PER_FACE_STEP = {16: 2.0765e9, 32: 8.2917e9}
 HBM_PEAK_GBS = 8000.0                                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")   # rocprofv3 --pmc passes (tools/pmc_traffic.py)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+# rocprofv3 --pmc passes of THIS bench command (tools/collect_profiles.sh + tools/pmc_traffic.py).  The file records the
+# hash of the kernel sources it was measured on; `roofline.traffic` is null when that differs from the sources in the tree.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_latest.json")
 
 
-def cpu_baseline(P, latent, kind, threads_note=True):
-    """Oracle timed on the host: batch 16, as-written forward (FPG + IDC + denoiser per step), fp32."""
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hifidiff_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(P, latent, n_diff, full_config1=True):
+    """The CPU oracle (a port of the reference's algorithm, fp32, torch-CPU) timed on this host's cores, bounded:
+    (1) BASELINE configs[0] in full when the latent is 16: 1 face, 50-step DDIM, as written (FPG + IDC + denoiser every step,
+        models/refiner.py:32-38 inside test_refiner.py:87-91);
+    (2) the bench workload's diffusion step at batch 16, as written, >= 10 timed evaluations, extrapolated to n_diff steps;
+    (3) the same with the conditioning hoisted out of the loop (denoiser + scheduler only), >= 10 evaluations."""
     from hifidiff_amd import synth
     from oracle import hifidiff_oracle as O
+    out = {}
+    if full_config1 and latent == 16:
+        x1, crl1, crf1 = synth.sample_inputs(1, latent)
+        sch = O.DDIMScheduler(clip_sample=True, clip_sample_range=3.0)
+        sch.set_timesteps(50)
+        O.refiner_forward(P, x1, torch.full((1,), 500), crf1, crl1)          # warm-up
+        t0 = time.time()
+        r = O.sample(P, x1, crf1, crl1, sch, "ddim", as_written=True)
+        dt = time.time() - t0
+        out["config1"] = {"value": round(1.0 / dt, 5), "unit": "faces/s", "seconds": round(dt, 3),
+                          "what": "BASELINE configs[0] run in full: 1 face, latent 16, 50-step DDIM eta 0 clip 3.0, as written "
+                                  "(FPG+IDC+denoiser every step), final |x| mean %.4f" % float(r.abs().mean())}
     B = 16
     x, crl, crf = synth.sample_inputs(B, latent)
     t = torch.full((B,), 500)
-    O.refiner_forward(P, x, t, crf, crl)                  # warm-up
-    n, t0 = 0, time.time()
-    while True:
-        eps = O.refiner_forward(P, x, t, crf, crl)
-        n += 1
-        if time.time() - t0 > 10.0 or n >= 20:
-            break
-    dt = (time.time() - t0) / n
-    return dt, B, n, float(eps.abs().mean())
+
+    def timed(fn, min_evals=10, budget=8.0, max_evals=40):
+        fn()                                                                   # warm-up
+        n, t0 = 0, time.time()
+        while n < min_evals or (time.time() - t0 < budget and n < max_evals):
+            fn()
+            n += 1
+        return (time.time() - t0) / n, n
+
+    dt_w, n_w = timed(lambda: O.refiner_forward(P, x, t, crf, crl))
+    cond = O.Conditioning(P, crl, crf)
+    dt_h, n_h = timed(lambda: O.fused_denoiser(P, x, t, cond=cond))
+    out["as_written"] = {"value": round(B / (dt_w * n_diff), 5), "unit": "faces/s", "s_per_diffusion_step": round(dt_w, 4), "batch": B, "evaluations": n_w}
+    out["hoisted"] = {"value": round(B / (dt_h * n_diff), 5), "unit": "faces/s", "s_per_diffusion_step": round(dt_h, 4), "batch": B, "evaluations": n_h}
+    return out
 
 
 def main():
@@ -72,11 +153,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+        raise SystemExit("bench.py rank %d/%d: --gpus %d does not match WORLD_SIZE %d" % (rank, world, a.gpus, world))
     torch.set_grad_enabled(False)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+        sys.stderr.write("bench.py rank %d/%d (local %d, master %s:%s): needs an MI355X (no CPU fallback exists for the product path)\n"
+                         % (rank, world, local, os.environ.get("MASTER_ADDR", "-"), os.environ.get("MASTER_PORT", "-")))
+        raise SystemExit(3)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -84,9 +166,10 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from hifidiff_amd import _lib, sampling, schedulers, synth
+    from hifidiff_amd import _lib, distributed, sampling, schedulers, synth
     from hifidiff_amd.refiner import FacialRefiner
 
     P = synth.refiner_state_dict(a.latent)
@@ -94,11 +177,12 @@ def main():
     model.load_state_dict(P)
     model.to(dev)
     B = a.batch
-    # this rank's faces of the global batch
+    # this rank's contiguous slice of the global batch (hifidiff_amd.distributed.shard_range)
+    lo, hi = distributed.shard_range(world * B, rank, world)
     x, crl, crf = [], [], []
     import numpy as np
     L = a.latent
-    for f in range(rank * B, rank * B + B):
+    for f in range(lo, hi):
         x.append(synth.randn(f"x_T/{f}", (4, L, L)))
         crl.append(np.float32(0.8) * synth.randn(f"cr_latent/{f}", (4, L, L)))
         crf.append(synth.rand(f"cr_face/{f}", (3, 128, 128)))
@@ -118,7 +202,6 @@ def main():
     Lh = _lib.lib()
     Lh.hd_set_profiling(model.engine.ctx, 1)
 
-    gathered = [torch.empty_like(x) for _ in range(world)] if use_dist else None
     if os.environ.get("HD_DUMP_OPS") and rank == 0:         # op order of one captured step, for tools/prof_summary.py
         model.prepare(crf, crl)
         with open(os.environ["HD_DUMP_OPS"], "w") as f:
@@ -127,9 +210,7 @@ def main():
 
     def one_pass(seed):
         out = sampling.sample(model, x, crf, crl, sch, noise=None, seed=seed)
-        if use_dist:
-            dist.all_gather(gathered, out)                 # result gather over RCCL/xGMI (4 KB per face)
-        return out
+        return distributed.gather_faces(out, world * B)    # result gather over RCCL/xGMI (4 KB per face); identity at N=1
 
     def fence():
         if use_dist:
@@ -140,7 +221,6 @@ def main():
         one_pass(1000 + w)
     fence()
     t0 = time.perf_counter()
-    step_ms = []
     for k in range(a.steps):
         out = one_pass(k + rank * 7919)
     fence()
@@ -150,52 +230,77 @@ def main():
     wbytes, fl = ctypes.c_int64(), ctypes.c_double()
     Lh.hd_get_profile(model.engine.ctx, ctypes.byref(loop_ms), ctypes.byref(step_ms_avg), ctypes.byref(wbytes), ctypes.byref(fl))
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = torch.tensor([hi - lo], dtype=torch.int64, device=dev)
+    rccl_world = 1
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        counts = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(counts, per_rank)
+        per_rank = torch.cat(counts)
+        rccl_world = dist.get_world_size()
     dt = float(tt.item())
     finite = bool(torch.isfinite(out).all().item())
 
     if rank == 0:
-        faces = world * B * a.steps
+        faces_per_rank = [int(v) for v in per_rank.tolist()]
+        faces = sum(faces_per_rank) * a.steps
         value = faces / dt
         alg_bytes = SURVEY_WEIGHT_BYTES.get(a.latent, float(wbytes.value))
         step_s = step_ms_avg.value * 1e-3
         achieved = alg_bytes / step_s / 1e9 if step_s > 0 else 0.0
-        traffic, traffic_src = None, None
-        if os.path.exists(TRAFFIC_FILE) and a.latent == 16 and B == 64 and a.kind == "ddpm":
+        flops_launch = SURVEY_FLOPS_PER_FACE_STEP.get(L, fl.value) * B
+        tflops = flops_launch / step_s / 1e12 if step_s > 0 else 0.0
+        traffic, traffic_src, measured_gbs = None, None, None
+        if os.path.exists(TRAFFIC_FILE) and B == 64 and world == 1:
             tj = json.load(open(TRAFFIC_FILE))
-            traffic, traffic_src = tj["hbm_bytes_per_step"], tj["source"]
+            if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("latent") == a.latent and tj.get("kind") == a.kind:
+                traffic, traffic_src = tj["hbm_bytes_per_step"], tj["source"]
+                measured_gbs = round(traffic / step_s / 1e9, 1) if step_s > 0 else None
+        headline = (L == 16 and a.kind == "ddpm" and n_diff == 1000 and B == 64)
+        cfg3 = (L == 32 and a.kind == "ddim" and n_diff == 250 and B == 64)
+        # which roofline bounds a step: weight streaming (HBM) at latent 16, MFMA at latent 32
+        hbm_bound = (alg_bytes / (HBM_PEAK_GBS * 1e9)) >= (flops_launch / (MFMA_BF16_PEAK_TFLOPS * 1e12))
+        if hbm_bound:
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)}
+        else:
+            roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)}
+        roof.update({"traffic": traffic, "traffic_source": traffic_src, "achieved_from_measured_traffic_GBs": measured_gbs,
+                     "kernel": "one captured step graph = one denoiser evaluation of the batch, scheduler update fused into its last launch",
+                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops_launch,
+                     "packed_weight_bytes_counted_by_library": int(wbytes.value),
+                     "avg_launch_ms": round(step_ms_avg.value, 4),
+                     "hbm_frac": round(achieved / HBM_PEAK_GBS, 4), "mfma_frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)})
         res = {
             "metric": "faces/sec (whole node), 16→128 1000-step reverse diffusion, batch 64",
             "value": round(value, 3), "unit": "faces/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%sbatch %d per GPU, latent %d (%d->%d px), %d-step %s "
-                                   "(clip 3.0%s), conditioning prologue included%s"
-                                   % ("BASELINE configs[1]: " if (L == 16 and a.kind == "ddpm" and n_diff == 1000 and B == 64) else
-                                      "BASELINE configs[3]: " if (L == 32 and a.kind == "ddim" and n_diff == 250 and B == 64) else "",
+                                   "(clip 3.0%s), conditioning prologue (FPG, ResNet-50 IDC, HCA gates, idc_conv) included%s"
+                                   % ("BASELINE configs[1]: " if (headline and world == 1) else
+                                      "BASELINE configs[2]: " if (headline and world == 8) else
+                                      "BASELINE configs[4] (IDC forward timed): " if (headline and world == 4) else
+                                      "BASELINE configs[3]: " if cfg3 else "",
                                       B, L, L, L * 8, n_diff, a.kind.upper(), ", fixed_small variance" if a.kind == "ddpm" else ", eta 0",
                                       ", device Philox noise" if a.kind == "ddpm" else ""),
-                       "faces_per_gpu": B, "latent_res": L, "diffusion_steps": n_diff, "sampler": a.kind,
-                       "parallelism": "batch-sharded x%d, no in-loop collective" % world,
+                       "faces_per_gpu": B, "faces_per_rank": faces_per_rank, "rccl_world_size": rccl_world,
+                       "launched_by": "bench.py self-launch" if os.environ.get("HD_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
+                       "latent_res": L, "diffusion_steps": n_diff, "sampler": a.kind,
+                       "parallelism": "batch-sharded x%d, no in-loop collective, one all_gather of the latents per pass" % world,
                        "concurrent_chains": Lh.hd_num_chains(model.engine.ctx),
                        "launches_per_diffusion_step": Lh.hd_num_ops(model.engine.ctx, 0) * Lh.hd_num_chains(model.engine.ctx),
                        "output_finite": finite},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "one captured step graph = one denoiser evaluation of the batch, scheduler update fused into its last launch",
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "packed_weight_bytes_counted_by_library": int(wbytes.value),
-                         "avg_launch_ms": round(step_ms_avg.value, 4),
-                         "mfma_frac": round(SURVEY_FLOPS_PER_FACE_STEP.get(L, fl.value) * B / step_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if step_s > 0 else None},
+            "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:              # the CPU leg is reported at N=1 only
-            sdt, sb, sn, _ = cpu_baseline(P, a.latent, a.kind)
+            cb = cpu_baseline(P, a.latent, n_diff)
             res["cpu_baseline"] = {
-                "value": round(sb / (sdt * n_diff), 5), "unit": "faces/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": "oracle refiner_forward as written (FPG+IDC+denoiser per step, fp32, torch-CPU), batch %d, "
-                          "%d evaluations after 1 warm-up: %.3f s per diffusion step, extrapolated x%d steps"
-                          % (sb, sn, sdt, n_diff)}
+                "value": cb["as_written"]["value"], "unit": "faces/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "oracle (torch-CPU fp32 port of the reference), the bench workload's diffusion step as written "
+                          "(FPG+IDC+denoiser per step, models/refiner.py:32-38), batch %d, %d timed evaluations after 1 warm-up: "
+                          "%.3f s per step, extrapolated x%d steps (per-step cost is constant)"
+                          % (cb["as_written"]["batch"], cb["as_written"]["evaluations"], cb["as_written"]["s_per_diffusion_step"], n_diff),
+                "hoisted": cb["hoisted"], "config1_full": cb.get("config1")}
         print(json.dumps(res))
     if use_dist:
         dist.barrier()

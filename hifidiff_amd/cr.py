@@ -103,9 +103,7 @@ class CoarseRestoration(nn.Module):
             raise RuntimeError("CoarseRestoration input must be (B,3,128,128), got %s" % (tuple(x.shape),))
         if B == 0:
             return torch.empty_like(x, dtype=torch.float32)
-        if self._batch is not None and self._batch != B:      # a context's workspace is sized by its first batch
-            self._upload()
-        self._batch = B
+        self._batch = B                                        # any batch size: the library keeps a workspace per recent size
         xin = x.to(device=self._device, dtype=torch.float32).contiguous()
         out = torch.empty_like(xin)
         with torch.cuda.device(self._device):

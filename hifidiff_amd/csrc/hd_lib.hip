@@ -98,6 +98,27 @@ struct Chain {
 
 static std::string g_create_error;
 
+// Everything whose size depends on the batch: buffers, launch programs, captured graphs.  One context serves any batch
+// size (the reference's val loop has a ragged last batch: DataLoader without drop_last, test_refiner.py:160): the
+// workspace of the batch in use lives in hd_ctx itself, workspaces of other recent batch sizes are parked here
+// (packed weights are shared and never touched).
+struct SavedWs {
+    int B = 0;
+    uint64_t stamp = 0;
+    std::vector<Chain> chains;
+    float *lat = nullptr, *eps = nullptr;
+    std::vector<void*> allocs;
+    std::map<std::string, std::pair<void*, std::pair<size_t, int>>> dbg;
+    bool graphs_valid = false;
+    const float* graph_film = nullptr;
+    int graph_B = 0;
+    // CoarseRestoration contexts
+    std::vector<Op> cr_program;
+    const float* cr_in = nullptr; float* cr_out = nullptr;
+    float* cr_skip[5] = {};
+    float *cr_loc1 = nullptr, *cr_loc2 = nullptr, *cr_theta = nullptr;
+};
+
 struct hd_ctx {
     int L = 16, device = 0, S = 1;            // S = L/16
     bool conditional = true;                  // false: the unconditional Denoiser (models/denoiser/model.py:32-134): no priors, HCAs or IDC
@@ -114,6 +135,10 @@ struct hd_ctx {
     std::string err;
     std::unordered_map<std::string, RawTensor> raw;
     std::vector<void*> allocs;
+    std::vector<void*> ws_allocs;             // allocations of the active batch workspace (dev_alloc while ws_scope)
+    bool ws_scope = false;
+    std::map<int, SavedWs> ws_cache;          // parked workspaces by batch size (at most kWsCached)
+    uint64_t ws_clock = 0;
     bool finalized = false;
 
     // weights
@@ -147,6 +172,14 @@ struct hd_ctx {
     int coef_cap = 0;
     int advance = 0;
     hipEvent_t fork_ev = nullptr;
+    // hd_sample never blocks on the caller's stream: the schedule is staged through two pinned buffers owned by the
+    // context (the one written two calls ago is reused; its copy-done event is the only thing ever waited for), and the
+    // FiLM table of a schedule is kept until a different schedule (or hd_eps) overwrites it.
+    struct Stage { float* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; } stage[2];
+    int stage_idx = 0;
+    std::vector<float> film_sched;            // timesteps whose rows film_table[0..n) currently holds
+    bool film_valid = false;
+    hipEvent_t film_ev = nullptr;
 
     // program
     int op_limit = -1, prep_limit = -1;
@@ -181,7 +214,7 @@ template <class T>
 int dev_alloc(hd_ctx* c, T** out, size_t count) {
     void* p = nullptr;
     HIPCHECK(c, hipMalloc(&p, count * sizeof(T) + 256));
-    c->allocs.push_back(p);
+    (c->ws_scope ? c->ws_allocs : c->allocs).push_back(p);
     *out = reinterpret_cast<T*>(p);
     return HD_OK;
 }
@@ -189,7 +222,66 @@ void dev_free(hd_ctx* c, void* p) {
     if (!p) return;
     for (auto& a : c->allocs)
         if (a == p) { a = nullptr; break; }
+    for (auto& a : c->ws_allocs)
+        if (a == p) { a = nullptr; break; }
     (void)hipFree(p);
+}
+
+constexpr size_t kWsCached = 3;
+void destroy_saved(SavedWs& w) {
+    for (auto& ch : w.chains) {
+        if (ch.graph_exec) (void)hipGraphExecDestroy(ch.graph_exec);
+        if (ch.stream) (void)hipStreamDestroy(ch.stream);
+        if (ch.done) (void)hipEventDestroy(ch.done);
+    }
+    for (void* p : w.allocs) if (p) (void)hipFree(p);
+    w.chains.clear(); w.allocs.clear();
+}
+// Park the active workspace under its batch size and make the context batch-less (B = 0).
+void park_workspace(hd_ctx* c) {
+    if (c->B == 0) return;
+    SavedWs w;
+    w.B = c->B; w.stamp = ++c->ws_clock;
+    w.chains = std::move(c->chains); w.lat = c->lat; w.eps = c->eps;
+    w.allocs = std::move(c->ws_allocs);
+    w.dbg = c->dbg;
+    w.graphs_valid = c->graphs_valid; w.graph_film = c->graph_film; w.graph_B = c->graph_B;
+    w.cr_program = std::move(c->cr_program); w.cr_in = c->cr_in; w.cr_out = c->cr_out;
+    for (int i = 0; i < 5; ++i) { w.cr_skip[i] = c->cr_skip[i]; c->cr_skip[i] = nullptr; }
+    w.cr_loc1 = c->cr_loc1; w.cr_loc2 = c->cr_loc2; w.cr_theta = c->cr_theta;
+    c->cr_loc1 = c->cr_loc2 = c->cr_theta = nullptr; c->cr_in = nullptr; c->cr_out = nullptr;
+    c->chains.clear(); c->ws_allocs.clear(); c->cr_program.clear();
+    c->lat = c->eps = nullptr; c->ch = nullptr;
+    for (auto it = c->dbg.begin(); it != c->dbg.end();) it = (it->first == "film" || it->first == "temb") ? std::next(it) : c->dbg.erase(it);
+    c->graphs_valid = false; c->prepared = false;
+    const int B = c->B;
+    c->B = 0;
+    c->ws_cache[B] = std::move(w);
+    while (c->ws_cache.size() > kWsCached) {                // evict the least recently used (its launches may still be in flight)
+        auto old = c->ws_cache.begin();
+        for (auto it = c->ws_cache.begin(); it != c->ws_cache.end(); ++it) if (it->second.stamp < old->second.stamp) old = it;
+        (void)hipDeviceSynchronize();
+        destroy_saved(old->second);
+        c->ws_cache.erase(old);
+    }
+}
+// Make the parked workspace of batch B active again; false if there is none.  The conditioning it holds belongs to an
+// older batch, so the context is "not prepared" afterwards.
+bool unpark_workspace(hd_ctx* c, int B) {
+    auto it = c->ws_cache.find(B);
+    if (it == c->ws_cache.end()) return false;
+    SavedWs& w = it->second;
+    c->chains = std::move(w.chains); c->lat = w.lat; c->eps = w.eps;
+    c->ws_allocs = std::move(w.allocs);
+    for (auto& kv : w.dbg) if (kv.first != "film" && kv.first != "temb") c->dbg[kv.first] = kv.second;
+    c->graphs_valid = w.graphs_valid; c->graph_film = w.graph_film; c->graph_B = w.graph_B;
+    c->cr_program = std::move(w.cr_program); c->cr_in = w.cr_in; c->cr_out = w.cr_out;
+    for (int i = 0; i < 5; ++i) c->cr_skip[i] = w.cr_skip[i];
+    c->cr_loc1 = w.cr_loc1; c->cr_loc2 = w.cr_loc2; c->cr_theta = w.cr_theta;
+    c->B = B; c->ch = c->chains.empty() ? nullptr : &c->chains[0];
+    c->prepared = false;
+    c->ws_cache.erase(it);
+    return true;
 }
 
 const RawTensor* find_raw(hd_ctx* c, const std::string& n) {
@@ -863,9 +955,18 @@ static void add_stn(hd_ctx* c, std::vector<Op>& prog, const std::string& name, c
     prog.back().out = Y; prog.back().out_elems = (size_t)lv.M * C;
 }
 
+static int alloc_cr_new(hd_ctx* c, int B);
 static int alloc_cr(hd_ctx* c, int B) {
     if (B == c->B) return HD_OK;
-    if (c->B != 0) HD_FAIL(c, HD_ERR_INVALID, "batch size change (%d -> %d) needs a new context", c->B, B);
+    park_workspace(c);
+    if (unpark_workspace(c, B)) return HD_OK;
+    c->ws_scope = true;
+    const int rc = alloc_cr_new(c, B);
+    c->ws_scope = false;
+    if (rc) { c->B = B; park_workspace(c); auto it = c->ws_cache.find(B); if (it != c->ws_cache.end()) { destroy_saved(it->second); c->ws_cache.erase(it); } }
+    return rc;
+}
+static int alloc_cr_new(hd_ctx* c, int B) {
     c->chains.resize(1);
     Chain& ch = c->chains[0];
     ch.index = 0; ch.B = B; ch.face0 = 0;
@@ -1007,9 +1108,18 @@ int build_denoiser_program(hd_ctx* c);
 
 // Cut the batch into chains (HD_CHAINS, default 1).  Two streams of these kernels do overlap (1.6x in
 // tools/gemm_bench), but halving M does not make a kernel cheaper, so splitting the batch is not a win.
+int alloc_workspace_new(hd_ctx* c, int B);
 int alloc_workspace(hd_ctx* c, int B) {
     if (B == c->B) return HD_OK;
-    if (c->B != 0) HD_FAIL(c, HD_ERR_INVALID, "batch size change (%d -> %d) needs a new context", c->B, B);
+    park_workspace(c);                                     // another batch size: keep its buffers, programs and graphs for later
+    if (unpark_workspace(c, B)) return HD_OK;
+    c->ws_scope = true;
+    const int rc = alloc_workspace_new(c, B);
+    c->ws_scope = false;
+    if (rc) { c->B = B; park_workspace(c); auto it = c->ws_cache.find(B); if (it != c->ws_cache.end()) { destroy_saved(it->second); c->ws_cache.erase(it); } }
+    return rc;
+}
+int alloc_workspace_new(hd_ctx* c, int B) {
     int n = 1;                                            // measured: per-kernel cost barely depends on M, so more chains only add launches
     if (const char* e = getenv("HD_CHAINS")) n = atoi(e);
     if (n < 1) n = 1;
@@ -1249,6 +1359,7 @@ int ensure_film_rows(hd_ctx* c, int rows) {
     rc |= dev_alloc(c, &c->film_table, (size_t)rows * c->film_total);
     if (rc) return rc;
     c->film_rows_cap = rows;
+    c->film_valid = false;
     c->dbg["film"] = {c->film_table, {(size_t)rows * c->film_total, 0}};
     c->dbg["temb"] = {c->temb_c, {(size_t)rows * 512, 0}};
     return HD_OK;
@@ -1341,10 +1452,14 @@ void hd_destroy(hd_ctx* c) {
         if (ch.done) (void)hipEventDestroy(ch.done);
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->film_ev) (void)hipEventDestroy(c->film_ev);
+    for (auto& sg : c->stage) { if (sg.ev) (void)hipEventDestroy(sg.ev); if (sg.host) (void)hipHostFree(sg.host); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto& kv : c->ws_cache) destroy_saved(kv.second);
     for (auto& kv : c->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (void* p : c->allocs) if (p) (void)hipFree(p);
+    for (void* p : c->ws_allocs) if (p) (void)hipFree(p);
     delete c;
 }
 
@@ -1702,6 +1817,7 @@ int hd_eps(hd_ctx* c, const float* x, const float* timesteps, int n_t, float* ep
     const size_t nlat = (size_t)c->B * 4 * c->L * c->L;
     HIPCHECK(c, hipMemcpyAsync(c->lat, x, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (auto& ch : c->chains) HIPCHECK(c, hipMemsetAsync(ch.step_state, 0, sizeof(StepState), s));
+    c->film_valid = false;                               // rows [0, n_t) are overwritten
     rc = compute_film(c, timesteps, n_t, s);
     if (rc) return rc;
     c->film_step_stride = 0;
@@ -1734,16 +1850,44 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
     }
     const size_t per_face = (size_t)4 * c->L * c->L;
     const size_t nlat = (size_t)c->B * per_face;
-    // schedule, FiLM table for every step, loop state (step = -1: each chain's intro kernel pre-increments)
-    HIPCHECK(c, hipMemcpyAsync(c->coef_dev, sched->coef, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
-    HIPCHECK(c, hipMemcpyAsync(c->t_dev, sched->timesteps, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+    // schedule and loop state (step = -1: each chain's intro kernel pre-increments) go through a pinned staging buffer of
+    // the context, so the caller's host arrays are free on return and nothing here waits for the stream
     StepState st{};
     st.step = -1; st.n_steps = n; st.noise = noise; st.seed = seed;
-    for (auto& ch : c->chains) HIPCHECK(c, hipMemcpyAsync(ch.step_state, &st, sizeof(st), hipMemcpyHostToDevice, s));
-    HIPCHECK(c, hipStreamSynchronize(s));                 // the host buffers above are caller/stack memory
-    HIPCHECK(c, hipMemcpyAsync(c->lat, x_inout, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
-    rc = compute_film(c, c->t_dev, n, s);
-    if (rc) return rc;
+    {
+        auto& sg = c->stage[c->stage_idx ^= 1];
+        const size_t st_f = (sizeof(StepState) + 3) / 4, need = (size_t)n * 8 + st_f;
+        if (sg.pending) { HIPCHECK(c, hipEventSynchronize(sg.ev)); sg.pending = false; }     // the copy issued two calls ago
+        if (sg.cap < need) {
+            if (sg.host) (void)hipHostFree(sg.host);
+            sg.host = nullptr; sg.cap = 0;
+            HIPCHECK(c, hipHostMalloc(reinterpret_cast<void**>(&sg.host), need * sizeof(float), hipHostMallocDefault));
+            sg.cap = need;
+        }
+        if (!sg.ev) HIPCHECK(c, hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
+        memcpy(sg.host, sched->coef, (size_t)n * 7 * sizeof(float));
+        memcpy(sg.host + (size_t)n * 7, sched->timesteps, (size_t)n * sizeof(float));
+        memcpy(sg.host + (size_t)n * 8, &st, sizeof(st));
+        HIPCHECK(c, hipMemcpyAsync(c->coef_dev, sg.host, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice, s));
+        for (auto& ch : c->chains) HIPCHECK(c, hipMemcpyAsync(ch.step_state, sg.host + (size_t)n * 8, sizeof(st), hipMemcpyHostToDevice, s));
+        const bool same_sched = c->film_valid && c->film_sched.size() == (size_t)n &&
+                                memcmp(c->film_sched.data(), sched->timesteps, (size_t)n * sizeof(float)) == 0;
+        if (!same_sched) HIPCHECK(c, hipMemcpyAsync(c->t_dev, sg.host + (size_t)n * 7, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHECK(c, hipEventRecord(sg.ev, s));
+        sg.pending = true;
+        HIPCHECK(c, hipMemcpyAsync(c->lat, x_inout, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (!same_sched) {                                // FiLM table of the whole schedule (0.5 GB at 1000 steps): once per schedule
+            c->film_valid = false;
+            rc = compute_film(c, c->t_dev, n, s);
+            if (rc) return rc;
+            if (!c->film_ev) HIPCHECK(c, hipEventCreateWithFlags(&c->film_ev, hipEventDisableTiming));
+            HIPCHECK(c, hipEventRecord(c->film_ev, s));
+            c->film_sched.assign(sched->timesteps, sched->timesteps + n);
+            c->film_valid = true;
+        } else {
+            HIPCHECK(c, hipStreamWaitEvent(s, c->film_ev, 0));       // no-op on the stream that computed it
+        }
+    }
     c->film_step_stride = c->film_total;
     c->film_face_stride = 0;
     c->film_from_cur = true;

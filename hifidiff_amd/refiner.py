@@ -15,9 +15,15 @@ for gfx950); PyTorch only owns the tensors and the stream.  There is no CPU path
 
 Deviation that is an optimisation, not a semantic change: the reference recomputes `fpg(cr_latent)`
 and `idc(cr_face)` on every forward although they are step-invariant (refiner.py:33-34); here the
-conditioning of a (cr_face, cr_latent) pair is computed once and reused while the same tensors (same
-storage, same version counter) are passed again.  `cache_conditioning=False` restores as-written
-behaviour.
+conditioning of a (cr_face, cr_latent) pair is computed once and reused while the SAME tensor objects
+(`is`, with unchanged version counters) are passed again -- the loop of `ddim_sample` passes the same
+two objects on every step.  The cache holds strong references to both tensors, so their storage cannot
+be recycled for another batch while the key is live; nothing is ever inferred from addresses.
+`cache_conditioning=False` restores as-written behaviour.
+
+One model instance serves any batch size (the ragged last batch of the reference's `val_loop`,
+test_refiner.py:98-112,160): the library keeps a workspace per recent batch size next to the shared
+packed weights.
 """
 import ctypes
 
@@ -147,14 +153,14 @@ class _Engine:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hd_prepare(self.ctx, B, crl.data_ptr(), crf.data_ptr() if crf is not None else None,
                                              emb.data_ptr() if emb is not None else None, _stream(self.device)), self.ctx)
-        self.batch = B
+        self.batch, self.cond_key = B, None
 
     def prepare_unconditional(self, batch):
         self.require_loaded()
         if self.batch != batch:
             with torch.cuda.device(self.device):
                 _lib.check(_lib.lib().hd_prepare_unconditional(self.ctx, batch, _stream(self.device)), self.ctx)
-            self.batch = batch
+            self.batch, self.cond_key = batch, None
 
     def prepare_from_priors(self, priors, id_emb):
         self.require_loaded()
@@ -362,12 +368,14 @@ class FacialRefiner(nn.Module):
         if tuple(cr_latent.shape) != (B, 4, L, L) or tuple(cr_face.shape) != (B, 3, 128, 128):
             raise RuntimeError("expected cr_latent (B,4,%d,%d) and cr_face (B,3,128,128), got %s and %s"
                                % (L, L, tuple(cr_latent.shape), tuple(cr_face.shape)))
-        key = (cr_face.data_ptr(), cr_face._version, tuple(cr_face.shape), tuple(cr_face.stride()),
-               cr_latent.data_ptr(), cr_latent._version, tuple(cr_latent.shape), tuple(cr_latent.stride()))
-        if self.cache_conditioning and e.cond_key == key and e.batch == cr_latent.shape[0]:
+        k = e.cond_key
+        if (self.cache_conditioning and k is not None and k[0] is cr_face and k[1] == cr_face._version
+                and k[2] is cr_latent and k[3] == cr_latent._version and e.batch == B):
             return
+        e.cond_key = None
         e.prepare(cr_latent, cr_face=cr_face)
-        e.cond_key = key
+        # strong references: identity + version, never addresses (a freed tensor's address is handed to the next batch)
+        e.cond_key = (cr_face, cr_face._version, cr_latent, cr_latent._version) if self.cache_conditioning else None
 
     def forward(self, latents, timesteps, cr_face, cr_latent):
         if latents.shape[0] == 0:                          # empty batch: like the reference's convs, an empty result

@@ -36,13 +36,14 @@ class _Base:
         self.init_noise_sigma = 1.0
         self.num_inference_steps = self.num_train_timesteps
         self.timesteps = torch.arange(self.num_train_timesteps - 1, -1, -1, dtype=torch.long)
-        self._step_index = {}
+        self._timesteps_set = False                        # diffusers' num_inference_steps is None until set_timesteps
 
     def set_timesteps(self, num_inference_steps, device=None):
         if num_inference_steps > self.num_train_timesteps:
             raise ValueError("num_inference_steps cannot exceed num_train_timesteps")
         r = self.num_train_timesteps // num_inference_steps
         self.num_inference_steps = int(num_inference_steps)
+        self._timesteps_set = True
         self.timesteps = (torch.arange(0, num_inference_steps, dtype=torch.long) * r).flip(0)   # 'leading', offset 0
         if device is not None:
             self.timesteps = self.timesteps.to(device)
@@ -72,6 +73,8 @@ class _Base:
     def _launch(self, eps, t, x, noise, seed, step):
         if not (x.is_cuda and eps.is_cuda):
             raise RuntimeError("hifidiff_amd schedulers run on the GPU only (no CPU fallback)")
+        if eps.device != x.device or (noise is not None and noise.is_cuda and noise.device != x.device):
+            raise RuntimeError("scheduler.step: sample, model_output and noise must live on one device (%s vs %s)" % (x.device, eps.device))
         x = x.contiguous().clone()
         eps = eps.contiguous().to(torch.float32)
         c = (ctypes.c_float * 7)(*self._coef(int(t)))
@@ -79,8 +82,9 @@ class _Base:
         if noise is not None:
             noise = noise.contiguous().to(device=x.device, dtype=torch.float32)
             nptr = noise.data_ptr()
-        rc = _lib.lib().hd_scheduler_step(x.data_ptr(), eps.data_ptr(), c, nptr, int(seed), int(step), x.numel(),
-                                          torch.cuda.current_stream(x.device).cuda_stream)
+        with torch.cuda.device(x.device):                  # the C function takes no context: launch on x's device and stream
+            rc = _lib.lib().hd_scheduler_step(x.data_ptr(), eps.data_ptr(), c, nptr, int(seed), int(step), x.numel(),
+                                              torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc)
         return SchedulerOutput(x)
 
@@ -95,6 +99,8 @@ class DDIMScheduler(_Base):
     def step(self, model_output, timestep, sample, eta=0.0, **kw):
         if eta != 0.0:
             raise NotImplementedError("only eta=0 (the reference's setting, test_refiner.py:91) is implemented")
+        if not self._timesteps_set:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         eps = getattr(model_output, "sample", model_output)
         return self._launch(eps, timestep, sample, None, 0, 0)
 
@@ -116,5 +122,6 @@ class DDPMScheduler(_Base):
     def step(self, model_output, timestep, sample, noise=None, seed=0, **kw):
         eps = getattr(model_output, "sample", model_output)
         ts = [int(v) for v in self.timesteps]
-        idx = ts.index(int(timestep)) if int(timestep) in ts else 0
-        return self._launch(eps, timestep, sample, noise, seed, idx)
+        if int(timestep) not in ts:                        # the Philox stream is keyed by the step's index in the schedule
+            raise ValueError("timestep %d is not in the current schedule (set_timesteps changed, or a stale t)" % int(timestep))
+        return self._launch(eps, timestep, sample, noise, seed, ts.index(int(timestep)))

@@ -106,17 +106,20 @@ def refiner_state_dict(latent_res=16, seed: int = WEIGHT_SEED, as_torch=True):
     return make_state_dict(arch.refiner_manifest(latent_res), seed, as_torch)
 
 
-def cr_state_dict(seed: int = WEIGHT_SEED):
+def cr_state_dict(seed: int = WEIGHT_SEED, wild: bool = False):
     """Synthetic CoarseRestoration weights (arch.cr_manifest).  The last Linear of every STN is scaled towards the
     identity transform the reference initialises it to (models/cr/stn.py:38-41), so theta stays a mild warp instead
-    of sampling mostly outside the image."""
+    of sampling mostly outside the image.  wild=True: strong warps instead (scales 0.6-1.4, shear and translation up
+    to ~0.4 of the half-width), so that a good part of every grid_sample lands outside the image (zero padding,
+    stn.py:43-52) and the bilinear footprints straddle the border."""
     import torch
     sd = make_state_dict(arch.cr_manifest(), seed)
     for k in sd:
         if k.endswith("stn.fc_loc.2.weight"):
             sd[k] = sd[k] * 0.05
         elif k.endswith("stn.fc_loc.2.bias"):
-            sd[k] = torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0]) + 0.02 * sd[k]
+            b = sd[k] / sd[k].abs().max().clamp_min(1e-12)            # in [-1, 1], deterministic per STN
+            sd[k] = torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0]) + (0.4 * b if wild else 0.02 * sd[k])
     return sd
 
 

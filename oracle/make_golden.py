@@ -131,6 +131,54 @@ def gen_cr(args):
 
 
 @torch.no_grad()
+def gen_cr_wild(args):
+    """CoarseRestoration with strong STN warps (synth.cr_state_dict(wild=True)): scales 0.6-1.4 and translations up to
+    0.4, so the affine grids of models/cr/stn.py:43-52 sample partly outside the image (zero padding)."""
+    import_reference(args.ref)
+    from models.cr.model import CoarseRestoration
+    net = CoarseRestoration().eval()
+    net.load_state_dict(synth.cr_state_dict(wild=True), strict=True)
+    x = T(np.stack([synth.rand(f"ln_face/{f}", (3, 128, 128)) for f in range(2)]))
+    thetas = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: thetas.append(out.detach().reshape(-1, 6).clone()))
+             for n, m in net.named_modules() if n.endswith("stn.fc_loc")]
+    out = {"out": net(x).numpy()}
+    for h in hooks:
+        h.remove()
+    out["thetas"] = torch.stack(thetas).numpy()                       # [9 STNs, 2 faces, 6]
+    th = torch.stack(thetas)
+    # fraction of grid points outside [-1, 1] for the first STN (128 x 128): must be substantial for the fixture to bite
+    g = torch.nn.functional.affine_grid(th[0].reshape(-1, 2, 3), (2, 1, 128, 128), align_corners=False)
+    out["outside_frac_stn0"] = np.float32(((g.abs() > 1).any(-1)).float().mean())
+    np.savez_compressed(os.path.join(args.out, "coarse_restoration_wild.npz"), **out)
+    print("wrote coarse_restoration_wild.npz", {k: getattr(v, "shape", v) for k, v in out.items()}, "outside", out["outside_frac_stn0"])
+
+
+@torch.no_grad()
+def gen_ddpm_slices(args):
+    """Two 20-step slices of the 1000-step DDPM schedule (clip 3.0, fixed_small variance, committed-seed noise), B=2, the
+    reference network inside the restated scheduler: the TAIL t = 19..0 (ends with the no-noise step t = 0) and a
+    MID-trajectory slice t = 519..500.  Start latents are synthetic ("x_tail/f" x 0.7, "x_mid/f")."""
+    FacialRefiner = import_reference(args.ref)[0]
+    net = FacialRefiner(16).eval()
+    net.load_state_dict(synth.refiner_state_dict(16), strict=True)
+    _, crl2, crf2 = synth.sample_inputs(2, 16)
+    out = {}
+    for name, first, scale in (("tail", 980, 0.7), ("mid", 480, 1.0)):
+        sch = O.DDPMScheduler(clip_sample=True, clip_sample_range=3.0)
+        ts = sch.timesteps[first:first + 20]
+        lat = T(np.stack([np.float32(scale) * synth.randn(f"x_{name}/{f}", (4, 16, 16)) for f in range(2)]))
+        for i, t in enumerate(ts):
+            eps = net(lat, torch.full((2,), t), crf2, crl2).sample
+            z = T(np.stack([synth.ddpm_noise(first + i, b, 16) for b in range(2)]))
+            lat = sch.step(eps, t, lat, noise=z).prev_sample
+        out[name] = lat.numpy()
+        out[name + "_t"] = np.array(ts)
+        print(name, ts[0], ts[-1], float(lat.abs().max()))
+    np.savez_compressed(os.path.join(args.out, "ddpm_slices_L16.npz"), **out)
+
+
+@torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -146,6 +194,10 @@ def main():
         return gen_cr(args)
     if args.only == "l32loop":
         return gen_l32_loop(args)
+    if args.only == "crwild":
+        return gen_cr_wild(args)
+    if args.only == "ddpmslices":
+        return gen_ddpm_slices(args)
     FacialRefiner, CondBlock, PosEmb, HCA = import_reference(args.ref)
 
     t0 = time.time()

@@ -58,12 +58,21 @@ def test_op_by_op_against_oracle(gpu, weights16, model2, inputs2):
     """Every launch of the prologue and of one denoiser evaluation vs the oracle tap of the same name."""
     import op_parity
     x, crl, crf = inputs2
-    for which, bound in ((1, 2.5e-2), (0, 2.5e-2)):
+    # Bound per launch: 1.5 x the emulation's own noise floor at that tap + 2.5e-3.  The floor is the bf16-operand oracle
+    # against itself on inputs perturbed by 2e-7: rounding decisions decorrelate once two evaluations differ by a fraction
+    # of a bf16 ulp, so ANY two correct evaluations drift apart along the same curve (1.0e-2 at middle_blks.7.conv5, measured
+    # on the oracle alone) -- the r01 "middle-level drift" of 1.3e-2 was this, not a kernel difference.  2.5e-3 covers the
+    # bf16 storage of G / G2 (the taps are unrounded fp32).  Early launches therefore have to be within 2.5e-3.
+    taps = op_parity.oracle_taps(weights16, x, crl, crf, 500.0)
+    floor = op_parity.noise_floor(weights16, x, crl, crf, 500.0, taps)
+    assert floor["denoiser.encoders.0.0.conv5"] < 1e-4 < floor["denoiser.middle_blks.7.conv5"] < 3e-2
+    for which in (1, 0):
         report = []
-        worst = op_parity.scan(model2, weights16, x, crl, crf, 500.0, report, which)
+        worst = op_parity.scan(model2, weights16, x, crl, crf, 500.0, report, which, taps, floor)
         bad = [r for r in report if "size" in r or "nan" in r]
         assert not bad, bad[:5]
-        assert worst <= bound, [r for r in report if "<<<<<<" in r][:10]
+        assert not [r for r in report if "<<<<<<" in r], [r for r in report if "<<<<<<" in r][:10]
+        assert worst <= 2.5e-2
     # the first block sees no accumulated drift: fp32-ordering noise only (bf16-stored buffers: one bf16 ulp)
     first = [r for r in report if "encoders.0.0." in r or r.split()[1] == "intro"]
     for r in first:
@@ -358,3 +367,174 @@ def test_graph_reuse_across_schedules(gpu, model2, inputs2):
     e1 = sampling.sample(model2, x, crf, crl, d, seed=5)
     e2 = sampling.sample(model2, x, crf, crl, d, seed=5)
     assert torch.equal(e1, e2) and bool(torch.isfinite(e1).all())
+
+
+def _read_dbg(model, name, n):
+    from hifidiff_amd import _lib
+    L = _lib.lib()
+    L.hd_debug_read.restype = ctypes.c_int64
+    have = L.hd_debug_read(model.engine.ctx, name.encode(), None, 0)
+    _lib.check(have, model.engine.ctx)
+    assert have >= n, (name, have, n)
+    buf = np.empty(have, dtype=np.float32)
+    _lib.check(L.hd_debug_read(model.engine.ctx, name.encode(), buf.ctypes.data_as(ctypes.c_void_p), have), model.engine.ctx)
+    return torch.from_numpy(buf[:n].copy())
+
+
+def test_time_embedding_and_film_table_against_reference_golden(gpu, weights16):
+    """SinusoidalPosEmb + time_mlp (models/denoiser/model.py:22-29,152-157) for t in {0, 1, 500, 999}: the device buffer
+    against the reference's own output, and the folded FiLM rows of every block (conditional_naf.py:103-115) against the
+    oracle's film_vectors + LayerNorm affine (the oracle reproduces the reference's blocks bit-exactly on CPU)."""
+    from hifidiff_amd import arch, synth
+    from oracle import hifidiff_oracle as O
+    g = golden("time_embedding.npz")
+    assert [float(v) for v in g["t"]] == [0.0, 1.0, 500.0, 999.0]
+    m = make_model(weights16)
+    x, crl, crf = [t.cuda() for t in synth.sample_inputs(4, 16)]
+    m(x, T(g["t"]).cuda(), crf, crl)                                   # per-face timesteps -> 4 FiLM rows
+    temb = _read_dbg(m, "temb", 4 * 512).reshape(4, 512)
+    assert rel_l2(temb, g["temb"]) <= 2e-5 and float((temb - T(g["temb"])).abs().max()) <= 1e-4
+    total = 124928                                                     # sum of 4C over the 32 blocks (SURVEY §2.1 K2)
+    film = _read_dbg(m, "film", 4 * total).reshape(4, total)
+    names = [f"denoiser.encoders.{l}.{j}" for l, n in enumerate((2, 2, 4, 8)) for j in range(n)]
+    names += [f"denoiser.middle_blks.{j}" for j in range(8)] + [f"denoiser.decoders.{l}.{j}" for l in range(4) for j in range(2)]
+    tref = O.time_embedding(weights16, T(g["t"]))
+    off = 0
+    for p in names:
+        sh_a, sc_a, sh_f, sc_f = [v.reshape(4, -1) for v in O.film_vectors(weights16, p, tref)]
+        C = sh_a.shape[1]
+        w1, b1, w2, b2 = [weights16[p + k] for k in (".norm1.weight", ".norm1.bias", ".norm2.weight", ".norm2.bias")]
+        want = torch.cat([b1 * (1 + sc_a) + sh_a, w1 * (1 + sc_a), b2 * (1 + sc_f) + sh_f, w2 * (1 + sc_f)], dim=1)
+        got = film[:, off:off + 4 * C]
+        assert rel_l2(got, want) <= 2e-5, p
+        off += 4 * C
+    assert off == total
+
+
+def test_conditioning_cache_keys_on_identity_not_addresses(gpu, weights16):
+    """The loop of ddim_sample passes the same (cr_face, cr_latent) objects on every step (cache hit); the next batch's
+    tensors are new objects that PyTorch's caching allocator may place at the freed addresses of the previous batch."""
+    from hifidiff_amd import synth
+    m = make_model(weights16)
+    fresh = make_model(weights16)
+    fresh.cache_conditioning = False
+    xs, crls, crfs = synth.sample_inputs(4, 16)
+    x = xs[:2].cuda()
+    t = torch.full((2,), 500, device="cuda")
+
+    def batch(lo):                                   # new out-of-place tensors, as cr_module(...) / vae.encode(...) return
+        return (crfs[lo:lo + 2].cuda() * 1.0), (crls[lo:lo + 2].cuda() * 1.0)
+    crf_a, crl_a = batch(0)
+    pa, pl = crf_a.data_ptr(), crl_a.data_ptr()
+    e_a = m(x, t, crf_a, crl_a).sample.clone()
+    assert torch.equal(m(x, t, crf_a, crl_a).sample, e_a)               # same objects: cached conditioning, same result
+    del crf_a, crl_a
+    crf_b, crl_b = batch(2)
+    reused = (crf_b.data_ptr() == pa, crl_b.data_ptr() == pl)            # typically (True, True); the test must pass either way
+    e_b = m(x, t, crf_b, crl_b).sample
+    want = fresh(x, t, crf_b, crl_b).sample
+    assert torch.equal(e_b, want), reused
+    assert rel_l2(e_b.cpu(), e_a.cpu()) > 1e-2                           # another person's priors give another eps
+    crf_b.mul_(0.5)                                                      # in-place edit bumps the version counter: recompute
+    assert not torch.equal(m(x, t, crf_b, crl_b).sample, want)
+
+
+def test_one_model_serves_a_ragged_val_loop(gpu, weights16):
+    """val_loop of test_refiner.py:98-112 iterates a DataLoader without drop_last (:160): batches 4, 4, 3 through ONE model
+    and ONE CoarseRestoration instance; results equal those of dedicated instances."""
+    from hifidiff_amd import sampling, schedulers, synth
+    from hifidiff_amd.cr import CoarseRestoration
+    m = make_model(weights16)
+    xs, crls, crfs = synth.sample_inputs(11, 16)
+    outs = []
+    for lo, hi in ((0, 4), (4, 8), (8, 11)):
+        sch = schedulers.DDIMScheduler(clip_sample_range=3.0)
+        outs.append(sampling.ddim_sample_eager(m, xs[lo:hi].cuda(), crfs[lo:hi].cuda(), crls[lo:hi].cuda(), sch, 4))
+    assert [o.shape[0] for o in outs] == [4, 4, 3] and all(bool(torch.isfinite(o).all()) for o in outs)
+    ded = make_model(weights16)
+    sch = schedulers.DDIMScheduler(clip_sample_range=3.0)
+    want = sampling.ddim_sample_eager(ded, xs[8:11].cuda(), crfs[8:11].cuda(), crls[8:11].cuda(), sch, 4)
+    assert torch.equal(outs[2], want)                                   # same kernels, same tiling: bit-identical
+    # back to the first batch size: the parked workspace (programs + graph) is reused and gives the first result again
+    sch = schedulers.DDIMScheduler(clip_sample_range=3.0)
+    again = sampling.ddim_sample_eager(m, xs[0:4].cuda(), crfs[0:4].cuda(), crls[0:4].cuda(), sch, 4)
+    assert torch.equal(again, outs[0])
+    sch.set_timesteps(4)
+    g4 = sampling.sample(m, xs[0:4].cuda(), crfs[0:4].cuda(), crls[0:4].cuda(), sch)
+    g3 = sampling.sample(m, xs[8:11].cuda(), crfs[8:11].cuda(), crls[8:11].cuda(), sch)
+    g4b = sampling.sample(m, xs[0:4].cuda(), crfs[0:4].cuda(), crls[0:4].cuda(), sch)
+    assert torch.equal(g4, g4b) and psnr(g3.cpu(), outs[2].cpu()) >= 50.0
+    model_fwd = m(xs[:1].cuda(), 500, crfs[:1].cuda(), crls[:1].cuda()).sample   # model(x[:1]) after a batch-4 call
+    assert tuple(model_fwd.shape) == (1, 4, 16, 16)
+    cr = CoarseRestoration()
+    cr.load_state_dict(synth.cr_state_dict())
+    cr.to("cuda:0")
+    ln = T(np.stack([synth.rand(f"ln_face/{f}", (3, 128, 128)) for f in range(3)]))
+    a3 = cr(ln.cuda()).clone()
+    a2 = cr(ln[:2].cuda()).clone()
+    b3 = cr(ln.cuda())
+    assert torch.equal(a3, b3) and psnr(a2.cpu(), a3[:2].cpu(), data_range=1.0) >= 50.0
+
+
+def test_scheduler_step_argument_checks(gpu):
+    from hifidiff_amd import schedulers
+    x, e = torch.randn(1, 4, 16, 16, device="cuda"), torch.randn(1, 4, 16, 16, device="cuda")
+    d = schedulers.DDPMScheduler(clip_sample_range=3.0)
+    d.set_timesteps(250)
+    with pytest.raises(ValueError):
+        d.step(e, 999, x)                                            # 999 is not in the 250-step schedule: no silent index 0
+    assert bool(torch.isfinite(d.step(e, 996, x, seed=3).prev_sample).all())
+    with pytest.raises(ValueError):
+        schedulers.DDIMScheduler(clip_sample_range=3.0).step(e, 980, x)   # set_timesteps was never called (diffusers raises too)
+
+
+def test_accelerate_prepare_leaves_the_mirror_unwrapped(gpu, weights16):
+    """accelerator.prepare(model) (test_refiner.py:173-174) wraps a model in DDP only if it has parameters that require
+    grad; the mirror owns its weights inside the library, so prepare() returns it as it is and the loop runs unchanged."""
+    accelerate = pytest.importorskip("accelerate")
+    m = make_model(weights16)
+    assert list(m.parameters()) == []
+    acc = accelerate.Accelerator()
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.arange(5)), batch_size=2)
+    m2, loader2 = acc.prepare(m, loader)
+    assert m2 is m
+    assert [int(b[0].numel()) for b in loader2] == [2, 2, 1]
+
+
+def test_ddpm_tail_and_mid_slices_against_reference_golden(gpu, model2):
+    """DDPM below t = 980: the last 20 steps (t = 19..0, the final step adds no noise) and t = 519..500, graph-replayed with
+    the committed noise, and the eager loop body (scheduler.step per iteration) for the tail."""
+    from hifidiff_amd import sampling, schedulers, synth
+    g = golden("ddpm_slices_L16.npz")
+    _, crl, crf = [t.cuda() for t in synth.sample_inputs(2, 16)]
+    for name, first, scale in (("tail", 980, 0.7), ("mid", 480, 1.0)):
+        sch = schedulers.DDPMScheduler(clip_sample_range=3.0)
+        sch.timesteps = sch.timesteps[first:first + 20]
+        assert [int(v) for v in sch.timesteps] == [int(v) for v in g[name + "_t"]]
+        x = T(np.stack([np.float32(scale) * synth.randn(f"x_{name}/{f}", (4, 16, 16)) for f in range(2)])).cuda()
+        noise = T(np.stack([np.stack([synth.ddpm_noise(first + i, b, 16) for b in range(2)]) for i in range(20)]))
+        out = sampling.sample(model2, x, crf, crl, sch, noise=noise).cpu()
+        assert psnr(out, g[name]) >= 40.0, (name, psnr(out, g[name]))
+        if name == "tail":
+            lat = x
+            for i, t in enumerate(sch.timesteps):
+                eps = model2(lat, torch.full((2,), int(t), device="cuda"), crf, crl).sample
+                lat = sch.step(eps, t, lat, noise=noise[i].cuda()).prev_sample
+            assert psnr(lat.cpu(), g[name]) >= 40.0 and psnr(lat.cpu(), out) >= 50.0
+            assert float(out.abs().max()) <= 3.0 + 1e-5             # t = 0: x_prev = mu, a blend of the clipped x0 and x
+
+
+def test_coarse_restoration_strong_warps_against_reference_golden(gpu):
+    """stn_grid_sample_kernel with 28 % of the samples outside the image (zero padding, models/cr/stn.py:43-52)."""
+    from hifidiff_amd import synth
+    from hifidiff_amd.cr import CoarseRestoration
+    from oracle import hifidiff_oracle as O
+    g = golden("coarse_restoration_wild.npz")
+    P = synth.cr_state_dict(wild=True)
+    m = CoarseRestoration()
+    m.load_state_dict(P)
+    m.to("cuda:0")
+    x = T(np.stack([synth.rand(f"ln_face/{f}", (3, 128, 128)) for f in range(2)]))
+    out = m(x.cuda()).cpu()
+    assert rel_l2(out, g["out"]) <= 1e-2
+    assert rel_l2(out, O.coarse_restoration(P, x, prec=O.BF16)) <= 6e-3

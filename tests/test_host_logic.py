@@ -110,6 +110,23 @@ def test_two_rank_shard_and_gather_gloo(tmp_path, n_faces):
     assert all(p.returncode == 0 for p in procs), outs
 
 
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` (the plain command the driver runs) starts two fresh workers BEFORE any GPU call:
+    without a GPU each worker reaches the "needs an MI355X" exit with RANK / WORLD_SIZE / MASTER_* set, and the
+    launcher returns non-zero because workers failed (reference: accelerator.prepare, test_refiner.py:173-174)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the workers would run the benchmark")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    for rank in (0, 1):
+        assert re.search(r"bench\.py rank %d/2 \(local %d, master 127\.0\.0\.1:\d+\): needs an MI355X" % (rank, rank), r.stderr), r.stderr
+    assert "ranks failed" in r.stderr and r.stdout.strip() == ""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "distributed.gather_faces(" in src and src.index("self_launch(_requested_gpus") < src.index("import torch  # noqa")
+
+
 def test_cr_manifest_and_synthetic_weights():
     """CoarseRestoration manifest (checked key-for-key against the reference in oracle/make_golden.py's container run):
     664 tensors, nine STN heads whose synthetic last Linear leans to the identity transform."""

@@ -133,3 +133,31 @@ def test_coarse_restoration():
     for k in ("encoders.3", "middle_blocks"):
         assert rel_l2(taps[k], g["feat." + k]) <= TOL32, k
     assert rel_l2(O.coarse_restoration(P, x, prec=O.BF16), g["out"]) <= 1e-2
+
+
+def test_coarse_restoration_strong_warps():
+    """STN grids that sample 28 % of their points outside the image (zero padding, models/cr/stn.py:43-52): the reference's
+    own output and its nine thetas."""
+    g = golden("coarse_restoration_wild.npz")
+    assert float(g["outside_frac_stn0"]) > 0.2
+    P = synth.cr_state_dict(wild=True)
+    x = torch.from_numpy(np.stack([synth.rand(f"ln_face/{f}", (3, 128, 128)) for f in range(2)]))
+    assert rel_l2(O.coarse_restoration(P, x), g["out"]) <= TOL32
+    th = g["thetas"]
+    assert th.shape == (9, 2, 6) and np.abs(th[:, :, [0, 4]] - 1).max() > 0.2      # scales far from the identity
+    assert rel_l2(O.coarse_restoration(P, x, prec=O.BF16), g["out"]) <= 1e-2
+
+
+def test_ddpm_tail_and_mid_slices(weights16):
+    """The last 20 steps of the 1000-step DDPM (t = 19..0, ends with the no-noise step) and a mid-trajectory slice
+    (t = 519..500): the reference network inside the restated scheduler."""
+    g = golden("ddpm_slices_L16.npz")
+    _, crl, crf = synth.sample_inputs(2, 16)
+    for name, first, scale in (("tail", 980, 0.7), ("mid", 480, 1.0)):
+        sch = O.DDPMScheduler(clip_sample=True, clip_sample_range=3.0)
+        sch.timesteps = sch.timesteps[first:first + 20]
+        assert sch.timesteps == [int(v) for v in g[name + "_t"]]
+        x = T(np.stack([np.float32(scale) * synth.randn(f"x_{name}/{f}", (4, 16, 16)) for f in range(2)]))
+        noise = lambda i: T(np.stack([synth.ddpm_noise(first + i, b, 16) for b in range(2)]))  # noqa: E731
+        lat = O.sample(weights16, x, crf, crl, sch, "ddpm", noise_fn=noise)
+        assert float((lat - T(g[name])).abs().max()) <= 1e-4, name

@@ -50,12 +50,35 @@ def compare(name, got, ref):
     return name, rel, float(d.abs().max()), ""
 
 
-def scan(model, P, x, crl, crf, t, report, which):
-    L = _lib.lib()
-    e = model.engine
+def oracle_taps(P, x, crl, crf, t):
     taps = {}
     cond = O.Conditioning(P, crl, crf, prec=O.BF16, taps=taps)
     O.fused_denoiser(P, x, t, cond=cond, prec=O.BF16, taps=taps)
+    return taps
+
+
+def noise_floor(P, x, crl, crf, t, taps, eps=2e-7):
+    """The emulation's own sensitivity: the same bf16-operand oracle on inputs perturbed by a relative 2e-7 (an fp32
+    accumulation-order difference).  Where two evaluations differ by more than a fraction of a bf16 ulp their operand
+    roundings decorrelate, so the difference grows tap by tap to ~1e-2 at the middle level with NO difference in the
+    arithmetic: a HIP-vs-oracle error is only meaningful relative to this curve (Oracle and parity)."""
+    g = torch.Generator().manual_seed(7)
+    pert = lambda v: v * (1 + eps * torch.randn(v.shape, generator=g))       # noqa: E731
+    other = oracle_taps(P, pert(x), pert(crl), pert(crf), t)
+    floor = {}
+    for k, v in taps.items():
+        d = (other[k].double() - v.double()).norm() / v.double().norm().clamp_min(1e-30)
+        floor[k] = float(d)
+    return floor
+
+
+def scan(model, P, x, crl, crf, t, report, which, taps=None, floor=None, slack=(1.5, 2.5e-3)):
+    """Returns the worst rel-L2 over the launches; with `floor` (noise_floor) also flags every launch whose error
+    exceeds slack[0] * floor + slack[1] (slack[1] covers the bf16 storage of G / G2 / pooled that the fp32 taps lack)."""
+    L = _lib.lib()
+    e = model.engine
+    if taps is None:
+        taps = oracle_taps(P, x, crl, crf, t)
     s = e.latent_res // 16
     worst = 0.0
     if which == 1:
@@ -74,9 +97,11 @@ def scan(model, P, x, crl, crf, t, report, which):
             report.append(f"{which}:{i:3d} {name:45s} (no tap)")
             continue
         nm, rel, mx, note = compare(name, read_op(L, e.ctx, which, i), to_rows(name, taps[name], s))
-        flag = "  <<<<<<" if not (rel < 5e-3) else ""
+        lim = 5e-3 if floor is None else slack[0] * floor.get(name, 0.0) + slack[1]
+        flag = "  <<<<<<" if not (rel < lim) else ""
         worst = max(worst, rel if rel == rel else 1e9)
-        report.append(f"{which}:{i:3d} {name:45s} rel {rel:.3e} maxabs {mx:.3e} {note}{flag}")
+        fl = "" if floor is None else f" floor {floor.get(name, 0.0):.3e} limit {lim:.3e}"
+        report.append(f"{which}:{i:3d} {name:45s} rel {rel:.3e} maxabs {mx:.3e}{fl} {note}{flag}")
     L.hd_debug_limit_ops(e.ctx, which, -1)
     if which == 1:
         e.prepare(crl, cr_face=crf)
@@ -103,9 +128,11 @@ def main():
     print(f"upload+pack {time.time() - t0:.1f}s", flush=True)
     x, crl, crf = synth.sample_inputs(a.batch, a.latent)
     report = []
-    w1 = scan(model, P, x, crl, crf, a.t, report, 1)
+    taps = oracle_taps(P, x, crl, crf, a.t)
+    floor = noise_floor(P, x, crl, crf, a.t, taps)
+    w1 = scan(model, P, x, crl, crf, a.t, report, 1, taps, floor)
     print(f"prologue worst rel {w1:.3e}", flush=True)
-    w0 = scan(model, P, x, crl, crf, a.t, report, 0)
+    w0 = scan(model, P, x, crl, crf, a.t, report, 0, taps, floor)
     print(f"step worst rel {w0:.3e}", flush=True)
     with open(a.out, "w") as f:
         f.write("\n".join(report) + "\n")
