@@ -16,7 +16,7 @@ import torch  # noqa: F401  (load order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhifidiff_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_gemm.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_gemm.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_tail.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
 
 EXPORTS = [
