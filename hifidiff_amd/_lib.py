@@ -16,11 +16,11 @@ import torch  # noqa: F401  (load order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhifidiff_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_gemm.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_tail.hpp")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_gemm.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_tail.hpp", "hd_vae.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
 
 EXPORTS = [
-    "hd_create", "hd_create_unconditional", "hd_prepare_unconditional", "hd_cr_create", "hd_cr_forward", "hd_destroy", "hd_last_error", "hd_load_weights", "hd_finalize_weights", "hd_prepare",
+    "hd_create", "hd_create_unconditional", "hd_prepare_unconditional", "hd_cr_create", "hd_cr_forward", "hd_vae_create", "hd_vae_encode", "hd_vae_decode", "hd_destroy", "hd_last_error", "hd_load_weights", "hd_finalize_weights", "hd_prepare",
     "hd_prepare_from_priors", "hd_fpg", "hd_idc", "hd_eps", "hd_sample", "hd_scheduler_step", "hd_num_ops", "hd_num_chains",
     "hd_debug_limit_ops", "hd_debug_op_name", "hd_debug_read_op", "hd_debug_read", "hd_set_profiling", "hd_get_profile",
 ]
@@ -67,6 +67,9 @@ def lib():
     L.hd_prepare_unconditional.argtypes = [vp, i32, vp]
     L.hd_cr_create.argtypes = [ctypes.POINTER(vp), i32]
     L.hd_cr_forward.argtypes = [vp, i32, vp, vp, vp]
+    L.hd_vae_create.argtypes = [ctypes.POINTER(vp), i32]
+    L.hd_vae_encode.argtypes = [vp, i32, i32, i32, vp, i32, vp, u64, vp, vp, vp]
+    L.hd_vae_decode.argtypes = [vp, i32, i32, vp, vp, vp]
     L.hd_destroy.argtypes = [vp]; L.hd_destroy.restype = None
     L.hd_last_error.argtypes = [vp]; L.hd_last_error.restype = ctypes.c_char_p
     L.hd_load_weights.argtypes = [vp, ctypes.POINTER(TensorDesc), i32]

@@ -219,3 +219,64 @@ def cr_manifest(prefix=""):
 def naf_levels(latent_res):
     """(channels, side) of the five UNet levels: C_l = 128*2^l, side = L/2^l."""
     return [(WIDTH << l, latent_res >> l) for l in range(5)]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# AutoencoderKL of "stable-diffusion-2-1-base" (the `vae` of test_refiner.py:176-178; SURVEY §8 f2).  diffusers 0.32.2
+# state-dict surface: block_out_channels (128, 256, 512, 512), layers_per_block 2, latent_channels 4, norm_num_groups 32,
+# one single-head attention (to_q / to_k / to_v / to_out.0 Linear) in each mid block.
+VAE_CHANNELS = (128, 256, 512, 512)
+VAE_SCALING = 0.18215
+
+
+def _gn(out, name, c):
+    out[name + ".weight"] = ((c,), "ln_w", 0)
+    out[name + ".bias"] = ((c,), "ln_b", 0)
+
+
+def _vae_resnet(out, p, cin, cout):
+    _gn(out, p + ".norm1", cin)
+    _conv(out, p + ".conv1", cout, cin, 3, 3)
+    _gn(out, p + ".norm2", cout)
+    _conv(out, p + ".conv2", cout, cout, 3, 3)
+    if cin != cout:
+        _conv(out, p + ".conv_shortcut", cout, cin, 1, 1)
+
+
+def _vae_attn(out, p, c):
+    _gn(out, p + ".group_norm", c)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        _linear(out, p + "." + n, c, c)
+
+
+def vae_manifest():
+    o = OrderedDict()
+    _conv(o, "encoder.conv_in", 128, 3, 3, 3)
+    cin = 128
+    for i, c in enumerate(VAE_CHANNELS):
+        for j in range(2):
+            _vae_resnet(o, f"encoder.down_blocks.{i}.resnets.{j}", cin, c)
+            cin = c
+        if i < 3:
+            _conv(o, f"encoder.down_blocks.{i}.downsamplers.0.conv", c, c, 3, 3)
+    _vae_resnet(o, "encoder.mid_block.resnets.0", 512, 512)
+    _vae_attn(o, "encoder.mid_block.attentions.0", 512)
+    _vae_resnet(o, "encoder.mid_block.resnets.1", 512, 512)
+    _gn(o, "encoder.conv_norm_out", 512)
+    _conv(o, "encoder.conv_out", 8, 512, 3, 3)
+    _conv(o, "quant_conv", 8, 8, 1, 1)
+    _conv(o, "post_quant_conv", 4, 4, 1, 1)
+    _conv(o, "decoder.conv_in", 512, 4, 3, 3)
+    _vae_resnet(o, "decoder.mid_block.resnets.0", 512, 512)
+    _vae_attn(o, "decoder.mid_block.attentions.0", 512)
+    _vae_resnet(o, "decoder.mid_block.resnets.1", 512, 512)
+    cin = 512
+    for i, c in enumerate(VAE_CHANNELS[::-1]):
+        for j in range(3):
+            _vae_resnet(o, f"decoder.up_blocks.{i}.resnets.{j}", cin, c)
+            cin = c
+        if i < 3:
+            _conv(o, f"decoder.up_blocks.{i}.upsamplers.0.conv", c, c, 3, 3)
+    _gn(o, "decoder.conv_norm_out", 128)
+    _conv(o, "decoder.conv_out", 3, 128, 3, 3)
+    return o

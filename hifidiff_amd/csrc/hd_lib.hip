@@ -20,6 +20,7 @@
 #include "hd_gemm.hpp"
 #include "hd_kernels.hpp"
 #include "hd_tail.hpp"
+#include "hd_vae.hpp"
 
 using namespace hd;
 
@@ -103,7 +104,12 @@ static std::string g_create_error;
 // size (the reference's val loop has a ragged last batch: DataLoader without drop_last, test_refiner.py:160): the
 // workspace of the batch in use lives in hd_ctx itself, workspaces of other recent batch sizes are parked here
 // (packed weights are shared and never touched).
+struct VaeWs { float *X = nullptr, *T = nullptr, *S = nullptr, *mom = nullptr, *Q = nullptr, *K = nullptr, *V = nullptr, *resz = nullptr, *out3 = nullptr;
+               unsigned short *H = nullptr, *H2 = nullptr, *Xb = nullptr, *U = nullptr; uint4* in8 = nullptr; double* part = nullptr; int B = 0, R = 0; };
+
 struct SavedWs {
+    VaeWs vws;
+    std::vector<Op> vae_enc_prog, vae_dec_prog;
     int B = 0;
     uint64_t stamp = 0;
     std::vector<Chain> chains;
@@ -182,6 +188,23 @@ struct hd_ctx {
     bool film_valid = false;
     hipEvent_t film_ev = nullptr;
 
+    // AutoencoderKL context (hd_vae_create)
+    bool vae = false;
+    struct VaeRes { std::string name; int cin = 0, cout = 0; PackedW c1, c2, sc; bool has_sc = false; const float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr; };
+    struct VaeAttn { std::string name; const float *gw = nullptr, *gb = nullptr; PackedW q, k, v, o; };
+    struct VaeW {
+        PackedW enc_in, enc_out, dec_in, dec_out, enc_down[3], dec_up[3];
+        VaeRes enc_res[4][2], enc_mid[2], dec_mid[2], dec_res[4][3];
+        VaeAttn enc_attn, dec_attn;
+        const float *enc_nw = nullptr, *enc_nb = nullptr, *dec_nw = nullptr, *dec_nb = nullptr;
+        const float *quant_w = nullptr, *quant_b = nullptr, *pq_w = nullptr, *pq_b = nullptr, *ones = nullptr;
+    } vw;
+    VaeWs vws;
+    std::vector<Op> vae_enc_prog, vae_dec_prog;
+    const void *vae_enc_key[4] = {}, *vae_dec_key[2] = {};
+    int vae_enc_flags = -1;
+    uint64_t vae_seed = 0;
+
     // persistent middle-level kernel (hd_tail.hpp): latent 16, batch <= 64, one chain, one FiLM row for all faces
     bool tail_ok = false;
     std::vector<TailBlockW> tail_blocks;
@@ -256,6 +279,11 @@ void park_workspace(hd_ctx* c) {
     w.dbg = c->dbg;
     w.graphs_valid = c->graphs_valid; w.graph_film = c->graph_film; w.graph_B = c->graph_B;
     w.cr_program = std::move(c->cr_program); w.cr_in = c->cr_in; w.cr_out = c->cr_out;
+    w.vws = c->vws; c->vws = VaeWs();
+    w.vae_enc_prog = std::move(c->vae_enc_prog); w.vae_dec_prog = std::move(c->vae_dec_prog);
+    c->vae_enc_prog.clear(); c->vae_dec_prog.clear();
+    for (auto& k : c->vae_enc_key) k = nullptr;
+    for (auto& k : c->vae_dec_key) k = nullptr;
     for (int i = 0; i < 5; ++i) { w.cr_skip[i] = c->cr_skip[i]; c->cr_skip[i] = nullptr; }
     w.cr_loc1 = c->cr_loc1; w.cr_loc2 = c->cr_loc2; w.cr_theta = c->cr_theta;
     c->cr_loc1 = c->cr_loc2 = c->cr_theta = nullptr; c->cr_in = nullptr; c->cr_out = nullptr;
@@ -285,6 +313,7 @@ bool unpark_workspace(hd_ctx* c, int B) {
     for (auto& kv : w.dbg) if (kv.first != "film" && kv.first != "temb") c->dbg[kv.first] = kv.second;
     c->graphs_valid = w.graphs_valid; c->graph_film = w.graph_film; c->graph_B = w.graph_B;
     c->cr_program = std::move(w.cr_program); c->cr_in = w.cr_in; c->cr_out = w.cr_out;
+    c->vws = w.vws;                                       // the VAE launch programs are rebuilt (they capture the caller's pointers)
     for (int i = 0; i < 5; ++i) c->cr_skip[i] = w.cr_skip[i];
     c->cr_loc1 = w.cr_loc1; c->cr_loc2 = w.cr_loc2; c->cr_theta = w.cr_theta;
     c->B = B; c->ch = c->chains.empty() ? nullptr : &c->chains[0];
@@ -549,6 +578,8 @@ hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStre
         return launch_skinny_auto<1, 1, false, LdBF16Plain, EpScaBF16>(p, s);   // its in-place G scaling is a skinny tile epilogue
     }
     if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, mode, s);
+    if (lk == LK_CONV_BF16 && ek == EK_RESID) return launch_tile<LdConv<true, false>, EpResidF32, false>(p, mode, s);      // VAE ResnetBlock2D conv2 + shortcut
+    if (lk == LK_BF16 && ek == EK_BIASF32) return launch_tile<LdBF16Plain, EpBiasF32, false>(p, mode, s);                  // VAE attention projections
     return hipErrorInvalidValue;
 }
 
@@ -1417,6 +1448,275 @@ int compute_film(hd_ctx* c, const float* t_dev, int n, hipStream_t s) {
 }
 
 
+
+// ============================================================================================ VAE boundary
+// AutoencoderKL of "stable-diffusion-2-1-base" (test_refiner.py:176-178): block_out_channels (128, 256, 512, 512),
+// layers_per_block 2, norm_num_groups 32, latent_channels 4, one attention head of 512 in each mid block
+// (diffusers 0.32.2 AutoencoderKL / Encoder / Decoder / ResnetBlock2D / Attention; third party, absent: parity unpinned).
+static void m_norm(std::vector<std::pair<std::string, Shape>>& m, const std::string& n, int c) { m.push_back({n + ".weight", {c}}); m.push_back({n + ".bias", {c}}); }
+static void m_vres(std::vector<std::pair<std::string, Shape>>& m, const std::string& p, int cin, int cout) {
+    m_norm(m, p + ".norm1", cin); m_conv(m, p + ".conv1", cout, cin, 3, 3); m_norm(m, p + ".norm2", cout); m_conv(m, p + ".conv2", cout, cout, 3, 3);
+    if (cin != cout) m_conv(m, p + ".conv_shortcut", cout, cin, 1, 1);
+}
+static void m_vattn(std::vector<std::pair<std::string, Shape>>& m, const std::string& p, int c) {
+    m_norm(m, p + ".group_norm", c); m_lin(m, p + ".to_q", c, c); m_lin(m, p + ".to_k", c, c); m_lin(m, p + ".to_v", c, c); m_lin(m, p + ".to_out.0", c, c);
+}
+static const int kVaeCh[4] = {128, 256, 512, 512};
+std::vector<std::pair<std::string, Shape>> build_vae_manifest() {
+    std::vector<std::pair<std::string, Shape>> m;
+    m_conv(m, "encoder.conv_in", 128, 3, 3, 3);
+    int cin = 128;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j) { m_vres(m, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, kVaeCh[i]); cin = kVaeCh[i]; }
+        if (i < 3) m_conv(m, "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", cin, cin, 3, 3);
+    }
+    m_vres(m, "encoder.mid_block.resnets.0", 512, 512); m_vattn(m, "encoder.mid_block.attentions.0", 512); m_vres(m, "encoder.mid_block.resnets.1", 512, 512);
+    m_norm(m, "encoder.conv_norm_out", 512); m_conv(m, "encoder.conv_out", 8, 512, 3, 3);
+    m_conv(m, "quant_conv", 8, 8, 1, 1); m_conv(m, "post_quant_conv", 4, 4, 1, 1);
+    m_conv(m, "decoder.conv_in", 512, 4, 3, 3);
+    m_vres(m, "decoder.mid_block.resnets.0", 512, 512); m_vattn(m, "decoder.mid_block.attentions.0", 512); m_vres(m, "decoder.mid_block.resnets.1", 512, 512);
+    cin = 512;
+    for (int i = 0; i < 4; ++i) {
+        const int cout = kVaeCh[3 - i];
+        for (int j = 0; j < 3; ++j) { m_vres(m, "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, cout); cin = cout; }
+        if (i < 3) m_conv(m, "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", cin, cin, 3, 3);
+    }
+    m_norm(m, "decoder.conv_norm_out", 128); m_conv(m, "decoder.conv_out", 3, 128, 3, 3);
+    return m;
+}
+
+static int finalize_vae(hd_ctx* c) {
+    const auto man = build_vae_manifest();
+    for (const auto& e : man) {
+        const RawTensor* r = find_raw(c, e.first);
+        if (!r) HD_FAIL(c, HD_ERR_WEIGHTS, "Missing key in state_dict: %s", e.first.c_str());
+        if (r->shape != e.second) HD_FAIL(c, HD_ERR_WEIGHTS, "size mismatch for %s", e.first.c_str());
+    }
+    if (c->raw.size() != man.size()) {
+        std::unordered_map<std::string, int> known;
+        for (const auto& e : man) known[e.first] = 1;
+        for (const auto& kv : c->raw)
+            if (!known.count(kv.first)) HD_FAIL(c, HD_ERR_WEIGHTS, "Unexpected key in state_dict: %s", kv.first.c_str());
+    }
+    auto& w = c->vw;
+    int rc = 0;
+    auto res = [&](const std::string& p, int cin, int cout, hd_ctx::VaeRes& r) {
+        r.name = p; r.cin = cin; r.cout = cout;
+        rc |= pack_weight(c, p + ".conv1", &r.c1); rc |= pack_weight(c, p + ".conv2", &r.c2);
+        r.has_sc = cin != cout;
+        if (r.has_sc) rc |= pack_weight(c, p + ".conv_shortcut", &r.sc);
+        r.n1w = find_raw(c, p + ".norm1.weight")->dev; r.n1b = find_raw(c, p + ".norm1.bias")->dev;
+        r.n2w = find_raw(c, p + ".norm2.weight")->dev; r.n2b = find_raw(c, p + ".norm2.bias")->dev;
+    };
+    auto attn = [&](const std::string& p, hd_ctx::VaeAttn& a) {
+        a.name = p; a.gw = find_raw(c, p + ".group_norm.weight")->dev; a.gb = find_raw(c, p + ".group_norm.bias")->dev;
+        rc |= pack_weight(c, p + ".to_q", &a.q); rc |= pack_weight(c, p + ".to_k", &a.k); rc |= pack_weight(c, p + ".to_v", &a.v); rc |= pack_weight(c, p + ".to_out.0", &a.o);
+    };
+    PackOpts pad8; pad8.cin_pad = 8;
+    rc |= pack_weight(c, "encoder.conv_in", &w.enc_in, pad8); rc |= pack_weight(c, "decoder.conv_in", &w.dec_in, pad8);
+    rc |= pack_weight(c, "encoder.conv_out", &w.enc_out); rc |= pack_weight(c, "decoder.conv_out", &w.dec_out);
+    int cin = 128;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j) { res("encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, kVaeCh[i], w.enc_res[i][j]); cin = kVaeCh[i]; }
+        if (i < 3) rc |= pack_weight(c, "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", &w.enc_down[i]);
+    }
+    res("encoder.mid_block.resnets.0", 512, 512, w.enc_mid[0]); attn("encoder.mid_block.attentions.0", w.enc_attn); res("encoder.mid_block.resnets.1", 512, 512, w.enc_mid[1]);
+    res("decoder.mid_block.resnets.0", 512, 512, w.dec_mid[0]); attn("decoder.mid_block.attentions.0", w.dec_attn); res("decoder.mid_block.resnets.1", 512, 512, w.dec_mid[1]);
+    cin = 512;
+    for (int i = 0; i < 4; ++i) {
+        const int cout = kVaeCh[3 - i];
+        for (int j = 0; j < 3; ++j) { res("decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, cout, w.dec_res[i][j]); cin = cout; }
+        if (i < 3) rc |= pack_weight(c, "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", &w.dec_up[i]);
+    }
+    if (rc) return rc;
+    w.enc_nw = find_raw(c, "encoder.conv_norm_out.weight")->dev; w.enc_nb = find_raw(c, "encoder.conv_norm_out.bias")->dev;
+    w.dec_nw = find_raw(c, "decoder.conv_norm_out.weight")->dev; w.dec_nb = find_raw(c, "decoder.conv_norm_out.bias")->dev;
+    w.quant_w = find_raw(c, "quant_conv.weight")->dev; w.quant_b = find_raw(c, "quant_conv.bias")->dev;
+    w.pq_w = find_raw(c, "post_quant_conv.weight")->dev; w.pq_b = find_raw(c, "post_quant_conv.bias")->dev;
+    rc = upload_vec(c, std::vector<float>(512, 1.0f), &w.ones);
+    if (rc) return rc;
+    HIPCHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&vae_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AT_SMEM));
+    HIPCHECK(c, hipDeviceSynchronize());
+    c->finalized = true;
+    return HD_OK;
+}
+
+static int alloc_vae_new(hd_ctx* c, int B, int R) {
+    auto& v = c->vws;
+    const size_t px = (size_t)B * R * R, big = px * 256, lat = (size_t)B * (R / 8) * (R / 8);
+    int rc = 0;
+    rc |= dev_alloc(c, &v.X, big); rc |= dev_alloc(c, &v.T, big); rc |= dev_alloc(c, &v.S, big);
+    rc |= dev_alloc(c, &v.H, big); rc |= dev_alloc(c, &v.H2, big); rc |= dev_alloc(c, &v.Xb, big); rc |= dev_alloc(c, &v.U, big);
+    rc |= dev_alloc(c, &v.in8, px); rc |= dev_alloc(c, &v.resz, px * 3); rc |= dev_alloc(c, &v.out3, px * 3);
+    rc |= dev_alloc(c, &v.mom, lat * 8); rc |= dev_alloc(c, &v.Q, lat * 512); rc |= dev_alloc(c, &v.K, lat * 512); rc |= dev_alloc(c, &v.V, lat * 512);
+    rc |= dev_alloc(c, &v.part, (size_t)B * ((size_t)R * R / 256 + 1) * GN_GROUPS * 2);
+    v.B = B; v.R = R;
+    return rc;
+}
+static int alloc_vae(hd_ctx* c, int B, int R) {
+    const int key = B + 8192 * (R / 8);
+    if (key == c->B) return HD_OK;
+    park_workspace(c);
+    if (unpark_workspace(c, key)) return HD_OK;
+    c->ws_scope = true;
+    const int rc = alloc_vae_new(c, B, R);
+    c->ws_scope = false;
+    c->B = key;
+    if (rc) { park_workspace(c); auto it = c->ws_cache.find(key); if (it != c->ws_cache.end()) { destroy_saved(it->second); c->ws_cache.erase(it); } }
+    return rc;
+}
+
+// ---- launch-program pieces (channels-last fp32 residual stream X [B*H*H][C]) ----
+static void vae_groupnorm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const float* x, const float* gw, const float* gb,
+                          unsigned short* y, int B, int H, int C, bool silu) {
+    const int HW = H * H, chunk = 256, nch = (HW + chunk - 1) / chunk;
+    double* part = c->vws.part;
+    prog.push_back({name, [=](hipStream_t s) -> hipError_t {
+                        hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(nch, B), dim3(256), 0, s, x, part, HW, C, chunk);
+                        hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(nch, B), dim3(256), 0, s, x, part, nch, gw, gb, y, HW, C, chunk, 1e-6f, silu ? 1 : 0);
+                        return hipGetLastError();
+                    }});
+    prog.back().out = y; prog.back().out_elems = (size_t)B * HW * C; prog.back().out_bf16 = 1;
+}
+// 3x3 conv (pad 1; stride 2: Downsample2D pads right/bottom only = reading zeros past the edge) on a bf16 channels-last map
+static void vae_conv3(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const PackedW& w, const unsigned short* in, int B, int Hin,
+                      int stride, float* out, const float* resid, unsigned short* out16) {
+    const int cin = w.K / 9, Hout = Hin / stride;
+    GemmP p = base_gemm(w, B * Hout * Hout);
+    p.A = in; p.lda = cin; p.Hin = Hin; p.Win = Hin; p.Cin = cin; p.KH = 3; p.KW = 3; p.stride = stride; p.pad = stride == 1 ? 1 : 0;
+    p.Hout = Hout; p.Wout = Hout; p.ntaps = 9;
+    p.out = out; p.ldo = w.N; p.out16 = out16;
+    if (resid) { p.resid = resid; p.ldr = w.N; p.rscale = c->vw.ones; add_gemm(c, prog, name, p, LK_CONV_BF16, EK_RESID); }
+    else add_gemm(c, prog, name, p, LK_CONV_BF16, EK_BIASF32);
+}
+static void vae_resnet(hd_ctx* c, std::vector<Op>& prog, const hd_ctx::VaeRes& r, int B, int H, unsigned short* out16) {
+    auto& v = c->vws;
+    vae_groupnorm(c, prog, r.name + ".norm1", v.X, r.n1w, r.n1b, v.H, B, H, r.cin, true);
+    vae_conv3(c, prog, r.name + ".conv1", r.c1, v.H, B, H, 1, v.T, nullptr, nullptr);
+    vae_groupnorm(c, prog, r.name + ".norm2", v.T, r.n2w, r.n2b, v.H2, B, H, r.cout, true);
+    const float* resid = v.X;
+    if (r.has_sc) {
+        GemmP p = base_gemm(r.sc, B * H * H);
+        p.A = v.X; p.lda = r.cin; p.out = v.S; p.ldo = r.cout;
+        add_gemm(c, prog, r.name + ".conv_shortcut", p, LK_F32, EK_BIASF32);
+        resid = v.S;
+    }
+    vae_conv3(c, prog, r.name + ".conv2", r.c2, v.H2, B, H, 1, v.X, resid, out16);
+}
+static void vae_attention(hd_ctx* c, std::vector<Op>& prog, const hd_ctx::VaeAttn& a, int B, int H) {
+    auto& v = c->vws;
+    const int T = H * H, M = B * T;
+    vae_groupnorm(c, prog, a.name + ".group_norm", v.X, a.gw, a.gb, v.H, B, H, 512, false);
+    const PackedW* ws[3] = {&a.q, &a.k, &a.v}; float* outs[3] = {v.Q, v.K, v.V}; const char* nm[3] = {".to_q", ".to_k", ".to_v"};
+    for (int i = 0; i < 3; ++i) {
+        GemmP p = base_gemm(*ws[i], M);
+        p.A = v.H; p.lda = 512; p.out = outs[i]; p.ldo = 512;
+        add_gemm(c, prog, a.name + nm[i], p, LK_BF16, EK_BIASF32);
+    }
+    {
+        const float *q = v.Q, *k = v.K, *vv = v.V; unsigned short* o = v.H2;
+        prog.push_back({a.name + ".softmax_qk_v", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(vae_attention_kernel, dim3((T + AT_Q - 1) / AT_Q, B), dim3(256), AT_SMEM, s, q, k, vv, o, T, 1.0f / sqrtf((float)AT_C));
+                            return hipGetLastError();
+                        }});
+        prog.back().out = o; prog.back().out_elems = (size_t)M * 512; prog.back().out_bf16 = 1;
+    }
+    GemmP p = base_gemm(a.o, M);
+    p.A = v.H2; p.lda = 512; p.out = v.X; p.ldo = 512; p.resid = v.X; p.ldr = 512; p.rscale = c->vw.ones;
+    add_gemm(c, prog, a.name + ".to_out.0", p, LK_BF16, EK_RESID);
+}
+
+static int build_vae_encode(hd_ctx* c, int B, int in_res, int R, const float* images, int vae_range, const float* noise, uint64_t seed,
+                            float* moments_out, float* latents_out) {
+    auto& prog = c->vae_enc_prog; prog.clear();
+    auto& v = c->vws; auto& w = c->vw;
+    const float* src = images;
+    if (in_res != R) {                                     // F.interpolate(x, R, mode="bicubic", align_corners=False) (test_refiner.py:80)
+        float* dst = v.resz; const int planes = B * 3;
+        prog.push_back({"bicubic", [=](hipStream_t s) -> hipError_t {
+                            const size_t n = (size_t)planes * R * R;
+                            hipLaunchKernelGGL(bicubic_resize_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, s, images, dst, planes, in_res, in_res, R, R);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = dst; prog.back().out_elems = (size_t)planes * R * R;
+        src = dst;
+    }
+    {
+        uint4* in8 = v.in8; const size_t npix = (size_t)B * R * R; const int HW = R * R;
+        prog.push_back({"encoder.input", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(nchw_to_nhwc8_bf16_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, src, in8, 3, HW, npix, vae_range);
+                            return hipGetLastError();
+                        }});
+    }
+    vae_conv3(c, prog, "encoder.conv_in", w.enc_in, reinterpret_cast<const unsigned short*>(v.in8), B, R, 1, v.X, nullptr, nullptr);
+    int H = R;
+    for (int i = 0; i < 4; ++i) {
+        vae_resnet(c, prog, w.enc_res[i][0], B, H, nullptr);
+        vae_resnet(c, prog, w.enc_res[i][1], B, H, i < 3 ? v.Xb : nullptr);
+        if (i < 3) { vae_conv3(c, prog, "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", w.enc_down[i], v.Xb, B, H, 2, v.X, nullptr, nullptr); H /= 2; }
+    }
+    vae_resnet(c, prog, w.enc_mid[0], B, H, nullptr);
+    vae_attention(c, prog, w.enc_attn, B, H);
+    vae_resnet(c, prog, w.enc_mid[1], B, H, nullptr);
+    vae_groupnorm(c, prog, "encoder.conv_norm_out", v.X, w.enc_nw, w.enc_nb, v.H, B, H, 512, true);
+    vae_conv3(c, prog, "encoder.conv_out", w.enc_out, v.H, B, H, 1, v.mom, nullptr, nullptr);
+    {
+        const float *mom = v.mom, *qw = w.quant_w, *qb = w.quant_b; const int HW = H * H; const size_t npix = (size_t)B * HW;
+        float* tmp = v.Q;                                  // quant_conv output when only the moments are wanted
+        prog.push_back({"quant_conv.sample", [=](hipStream_t s) -> hipError_t {
+                            if (latents_out)
+                                hipLaunchKernelGGL(vae_sample_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, mom, qw, qb, noise, (unsigned long long)seed, latents_out, HW, npix, 0.18215f, 8);
+                            if (moments_out)
+                                hipLaunchKernelGGL(vae_moments_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, mom, qw, qb, moments_out, HW, npix);
+                            (void)tmp;
+                            return hipGetLastError();
+                        }});
+        prog.back().out = latents_out ? latents_out : moments_out; prog.back().out_elems = npix * (latents_out ? 4 : 8);
+    }
+    return HD_OK;
+}
+
+static int build_vae_decode(hd_ctx* c, int B, int L, const float* latents, float* images_out) {
+    auto& prog = c->vae_dec_prog; prog.clear();
+    auto& v = c->vws; auto& w = c->vw;
+    int H = L;
+    {
+        uint4* in8 = v.in8; const float *pw = w.pq_w, *pb = w.pq_b; const int HW = H * H; const size_t npix = (size_t)B * HW;
+        prog.push_back({"post_quant_conv", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(vae_decode_entry_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, latents, pw, pb, in8, HW, npix, 1.0f / 0.18215f);
+                            return hipGetLastError();
+                        }});
+    }
+    vae_conv3(c, prog, "decoder.conv_in", w.dec_in, reinterpret_cast<const unsigned short*>(v.in8), B, H, 1, v.X, nullptr, nullptr);
+    vae_resnet(c, prog, w.dec_mid[0], B, H, nullptr);
+    vae_attention(c, prog, w.dec_attn, B, H);
+    vae_resnet(c, prog, w.dec_mid[1], B, H, nullptr);
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 3; ++j) vae_resnet(c, prog, w.dec_res[i][j], B, H, nullptr);
+        if (i < 3) {                                       // Upsample2D: nearest 2x, then conv 3x3
+            const float* x = v.X; unsigned short* u = v.U; const int C = w.dec_res[i][2].cout, Hc = H;
+            prog.push_back({"decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.nearest", [=](hipStream_t s) -> hipError_t {
+                                const size_t n = (size_t)B * 4 * Hc * Hc * (C / 8);
+                                hipLaunchKernelGGL(upsample2x_bf16_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, s, x, u, B, Hc, Hc, C);
+                                return hipGetLastError();
+                            }});
+            H *= 2;
+            vae_conv3(c, prog, "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", w.dec_up[i], v.U, B, H, 1, v.X, nullptr, nullptr);
+        }
+    }
+    vae_groupnorm(c, prog, "decoder.conv_norm_out", v.X, w.dec_nw, w.dec_nb, v.H, B, H, 128, true);
+    vae_conv3(c, prog, "decoder.conv_out", w.dec_out, v.H, B, H, 1, v.out3, nullptr, nullptr);
+    {
+        const float* o3 = v.out3; const int HW = H * H; const size_t npix = (size_t)B * HW;
+        prog.push_back({"decoder.output", [=](hipStream_t s) -> hipError_t {
+                            hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((npix * 3 + 255) / 256)), dim3(256), 0, s, o3, images_out, 3, 3, HW, npix);
+                            return hipGetLastError();
+                        }});
+        prog.back().out = images_out; prog.back().out_elems = npix * 3;
+    }
+    return HD_OK;
+}
+
 // Persistent middle level (hd_tail.hpp): second packing of the 8 middle blocks' 1x1 weights in the 16x16x32 B-fragment
 // order, the blocks' pointer table and the hand-off workspace (sized for 64 rows: independent of the batch).
 static int pack_frag16(hd_ctx* c, const std::string& name, const uint4** out) {
@@ -1522,6 +1822,52 @@ int hd_cr_forward(hd_ctx* c, int batch, const float* ln_face, float* cr_face_out
     return run_ops(c, c->cr_program, reinterpret_cast<hipStream_t>(stream), c->op_limit);
 }
 
+// AutoencoderKL boundary.  encode: images [B,3,in_res,in_res] fp32 NCHW -> bicubic to image_res (test_refiner.py:80)
+// -> encoder -> quant_conv; moments_out [B,8,L,L] (mean | logvar) and / or latents_out [B,4,L,L] =
+// latent_dist.sample() * 0.18215 (noise [B,4,L,L] or device Philox(seed)).  vae_range 1: clamp(0,1)*2-1 first
+// (train_refiner.py:72-83).  decode: latents [B,4,L,L] -> decode(latents / 0.18215).sample [B,3,8L,8L] (test_refiner.py:93).
+int hd_vae_create(hd_ctx** out, int device) {
+    int rc = hd_create(out, 16, device);
+    if (rc == HD_OK) { (*out)->vae = true; (*out)->conditional = false; }
+    return rc;
+}
+int hd_vae_encode(hd_ctx* c, int batch, int in_res, int image_res, const float* images, int vae_range, const float* noise, uint64_t seed,
+                  float* moments_out, float* latents_out, void* stream) {
+    if (!c) return HD_ERR_INVALID;
+    if (!c->vae) HD_FAIL(c, HD_ERR_INVALID, "hd_vae_encode: not an AutoencoderKL context (hd_vae_create)");
+    if (!c->finalized) HD_FAIL(c, HD_ERR_NOT_READY, "weights are not loaded/finalized");
+    if (!images || (!moments_out && !latents_out) || batch <= 0 || batch > 1024 || in_res < 8 || image_res < 64 || image_res > 512 || image_res % 64)
+        HD_FAIL(c, HD_ERR_INVALID, "hd_vae_encode: bad arguments (image_res must be a multiple of 64 in [64, 512])");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = alloc_vae(c, batch, image_res);
+    if (rc) return rc;
+    const void* key[4] = {images, noise, moments_out, latents_out};
+    const int flags = in_res * 4 + vae_range * 2;
+    if (c->vae_enc_prog.empty() || memcmp(key, c->vae_enc_key, sizeof(key)) != 0 || flags != c->vae_enc_flags || seed != c->vae_seed) {
+        rc = build_vae_encode(c, batch, in_res, image_res, images, vae_range, noise, seed, moments_out, latents_out);
+        if (rc) return rc;
+        memcpy(c->vae_enc_key, key, sizeof(key)); c->vae_enc_flags = flags;
+    }
+    c->vae_seed = seed;
+    return run_ops(c, c->vae_enc_prog, reinterpret_cast<hipStream_t>(stream), c->op_limit);
+}
+int hd_vae_decode(hd_ctx* c, int batch, int latent_res, const float* latents, float* images_out, void* stream) {
+    if (!c) return HD_ERR_INVALID;
+    if (!c->vae) HD_FAIL(c, HD_ERR_INVALID, "hd_vae_decode: not an AutoencoderKL context (hd_vae_create)");
+    if (!c->finalized) HD_FAIL(c, HD_ERR_NOT_READY, "weights are not loaded/finalized");
+    if (!latents || !images_out || batch <= 0 || batch > 1024 || latent_res < 8 || latent_res > 64 || latent_res % 8) HD_FAIL(c, HD_ERR_INVALID, "hd_vae_decode: bad arguments");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = alloc_vae(c, batch, latent_res * 8);
+    if (rc) return rc;
+    const void* key[2] = {latents, images_out};
+    if (c->vae_dec_prog.empty() || memcmp(key, c->vae_dec_key, sizeof(key)) != 0) {
+        rc = build_vae_decode(c, batch, latent_res, latents, images_out);
+        if (rc) return rc;
+        memcpy(c->vae_dec_key, key, sizeof(key));
+    }
+    return run_ops(c, c->vae_dec_prog, reinterpret_cast<hipStream_t>(stream), c->op_limit);
+}
+
 int hd_create(hd_ctx** out, int latent_res, int device) {
     if (!out) return HD_ERR_INVALID;
     *out = nullptr;
@@ -1604,6 +1950,7 @@ int hd_finalize_weights(hd_ctx* c) {
     if (c->finalized) return HD_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     if (c->cr) return finalize_cr(c);
+    if (c->vae) return finalize_vae(c);
     // ---- strict key / shape check ----
     const auto man = build_manifest(c->L, c->conditional);
     for (const auto& e : man) {
@@ -2044,6 +2391,7 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
 static std::vector<Op>* which_program(hd_ctx* c, int which) {
     static std::vector<Op> empty;
     if (c->cr) return &c->cr_program;
+    if (c->vae) return which == 0 ? &c->vae_enc_prog : &c->vae_dec_prog;
     if (c->chains.empty()) return &empty;
     return which == 0 ? &c->chains[0].program : &c->chains[0].prep_program;
 }

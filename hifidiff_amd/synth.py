@@ -123,6 +123,11 @@ def cr_state_dict(seed: int = WEIGHT_SEED, wild: bool = False):
     return sd
 
 
+def vae_state_dict(seed: int = WEIGHT_SEED):
+    """Synthetic AutoencoderKL weights (arch.vae_manifest: 83.7 M parameters; the SD-2.1 checkpoint is not reachable offline)."""
+    return make_state_dict(arch.vae_manifest(), seed)
+
+
 # ---------------------------------------------------------------- synthetic inputs
 def randn(tag: str, shape, seed: int = INPUT_SEED):
     n = int(np.prod(shape))

@@ -67,6 +67,21 @@ int hd_create_unconditional(hd_ctx** out, int latent_res, int device);
  *   hd_cr_forward(ctx, B, ln_face [B,3,128,128], cr_face_out [B,3,128,128], stream). */
 int hd_cr_create(hd_ctx** out, int device);
 int hd_cr_forward(hd_ctx* ctx, int batch, const float* ln_face, float* cr_face_out, void* stream);
+
+/* VAE boundary either side of the loop: replaces
+ *   cr_latent = vae.encode(F.interpolate(cr_face, image_res, mode="bicubic")).latent_dist.sample() * 0.18215
+ *                                                              (test_refiner.py:78-83; train_refiner.py:72-83 with to_vae_range)
+ *   images    = vae.decode(latent / 0.18215).sample            (test_refiner.py:93; train_refiner.py:122-123)
+ * with diffusers' AutoencoderKL of "stable-diffusion-2-1-base" (third party; weights come from the caller's state dict with
+ * diffusers' key names, loaded with hd_load_weights / hd_finalize_weights on a context from hd_vae_create).
+ *   hd_vae_encode: images [B,3,in_res,in_res] fp32 NCHW; bicubic (align_corners=False) to image_res when they differ;
+ *                  vae_range 1 applies clamp(0,1)*2-1 first; moments_out [B,8,L,L] (mean | logvar of the posterior) and / or
+ *                  latents_out [B,4,L,L] = (mean + std * z) * 0.18215 with z = noise [B,4,L,L] or device Philox(seed); L = image_res/8.
+ *   hd_vae_decode: latents [B,4,L,L] -> images_out [B,3,8L,8L]. */
+int hd_vae_create(hd_ctx** out, int device);
+int hd_vae_encode(hd_ctx* ctx, int batch, int in_res, int image_res, const float* images, int vae_range, const float* noise, uint64_t seed,
+                  float* moments_out, float* latents_out, void* stream);
+int hd_vae_decode(hd_ctx* ctx, int batch, int latent_res, const float* latents, float* images_out, void* stream);
 void hd_destroy(hd_ctx* ctx);
 const char* hd_last_error(const hd_ctx* ctx);   /* ctx may be NULL: creation errors */
 

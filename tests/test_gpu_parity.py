@@ -568,3 +568,43 @@ def test_persistent_middle_level_against_per_gemm_launches(gpu, weights16):
     b = sampling.sample(m, x, crf, crl, sch, seed=3)
     c0 = sampling.sample(m0, x, crf, crl, sch, seed=3)
     assert torch.equal(a, b) and psnr(a.cpu(), c0.cpu()) >= 50.0
+
+
+def test_vae_boundary_against_oracle(gpu):
+    """bicubic resize -> AutoencoderKL.encode -> posterior sample -> x 0.18215 and / 0.18215 -> decode
+    (test_refiner.py:78-83,93) through hd_vae_encode / hd_vae_decode against the CPU restatement of diffusers' AutoencoderKL
+    (PARITY UNPINNED: diffusers and the SD-2.1 checkpoint are absent; synthetic weights).  Tolerances: bf16 operands against
+    the bf16-emulating oracle 1.5e-2 (moments) / 2.5e-2 (images); against the fp32 oracle 2.5e-2 / 4e-2."""
+    from hifidiff_amd import synth
+    from hifidiff_amd.vae import AutoencoderKL
+    from oracle import hifidiff_oracle as O
+    P = synth.vae_state_dict()
+    vae = AutoencoderKL()
+    with pytest.raises(RuntimeError):
+        vae.load_state_dict({k: v for k, v in P.items() if k != "quant_conv.bias"})      # strict: missing key
+    vae.load_state_dict(P)
+    vae.to("cuda:0")
+    x = T(np.stack([synth.rand(f"cr_face_vae/{f}", (3, 128, 128)) for f in range(2)]))
+    post = vae.encode(x.cuda()).latent_dist                                              # the reference's call form
+    m32, m16 = O.vae_encode_moments(P, x), O.vae_encode_moments(P, x, O.BF16)
+    assert tuple(post.parameters.shape) == (2, 8, 16, 16)
+    assert rel_l2(post.parameters.cpu(), m16) <= 1.5e-2 and rel_l2(post.parameters.cpu(), m32) <= 2.5e-2
+    assert tuple(post.sample().shape) == (2, 4, 16, 16) and torch.equal(post.mode(), post.mean)
+    nz = T(np.stack([synth.randn(f"vae_noise/{f}", (4, 16, 16)) for f in range(2)]))
+    lat = vae.encode_scaled(x.cuda(), 128, noise=nz.cuda())
+    assert rel_l2(lat.cpu(), O.vae_encode_scaled(P, x, 128, nz, prec=O.BF16)) <= 1.5e-2
+    a, b = vae.encode_scaled(x.cuda(), 128, seed=5), vae.encode_scaled(x.cuda(), 128, seed=5)
+    assert torch.equal(a, b) and not torch.equal(a, vae.encode_scaled(x.cuda(), 128, seed=6))   # device Philox noise
+    # decode, both call forms
+    z = T(np.stack([np.float32(0.8) * synth.randn(f"vae_z/{f}", (4, 16, 16)) for f in range(2)]))
+    img = vae.decode_scaled(z.cuda()).cpu()
+    assert tuple(img.shape) == (2, 3, 128, 128)
+    assert rel_l2(img, O.vae_decode_scaled(P, z, O.BF16)) <= 2.5e-2 and rel_l2(img, O.vae_decode_scaled(P, z)) <= 4e-2
+    assert torch.equal(vae.decode(z.cuda() / 0.18215).sample.cpu(), img)
+    # 32 -> 256: bicubic upscale of the 128 x 128 CR output (latent 32), train_refiner.py's to_vae_range variant, one face
+    lat32 = vae.encode_scaled(x[:1].cuda(), 256, vae_range=True, noise=torch.zeros(1, 4, 32, 32))
+    want = O.vae_encode_scaled(P, x[:1], 256, torch.zeros(1, 4, 32, 32), vae_range=True, prec=O.BF16)
+    assert tuple(lat32.shape) == (1, 4, 32, 32) and rel_l2(lat32.cpu(), want) <= 1.5e-2
+    with pytest.raises(RuntimeError):
+        vae.encode(x[:, :2].cuda())                                                      # wrong channel count
+    assert tuple(vae.decode_scaled(z[:0].cuda()).shape) == (0, 3, 128, 128)

@@ -161,3 +161,24 @@ def test_ddpm_tail_and_mid_slices(weights16):
         noise = lambda i: T(np.stack([synth.ddpm_noise(first + i, b, 16) for b in range(2)]))  # noqa: E731
         lat = O.sample(weights16, x, crf, crl, sch, "ddpm", noise_fn=noise)
         assert float((lat - T(g[name])).abs().max()) <= 1e-4, name
+
+
+def test_vae_restatement_is_self_consistent():
+    """SURVEY §8 f2, PARITY UNPINNED (diffusers 0.32.2 and the SD-2.1 VAE checkpoint are absent; the reference holds no fixture):
+    shapes, parameter count of the published architecture, determinism, and the properties the boundary relies on."""
+    man = arch.vae_manifest()
+    assert len(man) == 248 and sum(int(np.prod(s)) for s, _, _ in man.values()) == 83_653_863      # SD VAE: 83.65 M parameters
+    assert man["encoder.mid_block.attentions.0.to_q.weight"][0] == (512, 512) and man["decoder.up_blocks.2.resnets.0.conv_shortcut.weight"][0] == (256, 512, 1, 1)
+    P = synth.vae_state_dict()
+    x = T(synth.rand("vae_in/0", (1, 3, 64, 64)))
+    m = O.vae_encode_moments(P, x)
+    assert tuple(m.shape) == (1, 8, 8, 8) and torch.equal(m, O.vae_encode_moments(P, x))
+    z0 = O.vae_encode_scaled(P, x, 64, torch.zeros(1, 4, 8, 8))
+    assert torch.allclose(z0, m[:, :4] * 0.18215)                                                  # zero noise: the scaled mean
+    z1 = O.vae_encode_scaled(P, x, 64, torch.ones(1, 4, 8, 8))
+    assert torch.allclose(z1 - z0, torch.exp(0.5 * m[:, 4:].clamp(-30, 20)) * 0.18215, atol=1e-6)
+    y = O.vae_decode_scaled(P, z0)
+    assert tuple(y.shape) == (1, 3, 64, 64) and bool(torch.isfinite(y).all())
+    assert rel_l2(O.vae_encode_moments(P, x, O.BF16), m) <= 2e-2
+    up = O.vae_encode_scaled(P, x, 128, torch.zeros(1, 4, 16, 16), vae_range=True)                  # bicubic 64 -> 128 + to_vae_range
+    assert tuple(up.shape) == (1, 4, 16, 16)
