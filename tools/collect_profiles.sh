@@ -3,7 +3,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r01'
 # Outputs land in gpurun_out/<round>/ ; copy the summaries into profiles/ afterwards (see the end of this file).
 set -e -o pipefail
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
@@ -34,7 +34,20 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python tools/pmc_traffic.py "$A" 10 "$B" 30 $C "$OUT/traffic.json" | tee -a "$OUT/traffic.txt"
   rm -rf "$OUT/pmc_${C}_10" "$OUT/pmc_${C}_30"
 done
-cp "$OUT/traffic.json" "$ROOT/profiles/${R}_traffic.json"      # bench.py reads profiles/<round>_traffic.json
+python - "$OUT/traffic.json" "$ROOT/profiles/${R}_traffic.json" "$ROOT/profiles/traffic_latest.json" <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", "bench.py"); b = importlib.util.module_from_spec(spec)
+src = open("bench.py").read()
+ns = {}
+exec(src[src.index("def kernel_source_hash"):src.index("def cpu_baseline")], {"os": __import__("os"), "ROOT": "."}, ns)
+j = json.load(open(sys.argv[1]))
+j["kernel_source_hash"] = ns["kernel_source_hash"](); j["latent"] = 16; j["kind"] = "ddpm"
+for out in sys.argv[2:]:
+    json.dump(j, open(out, "w"), indent=1)
+PY
+# bench.py reads profiles/traffic_latest.json and reports it only while the kernel sources still hash to the recorded value
 
 # 3. the headline bench line (includes the cpu_baseline leg)
 timeout -k 10 600 python bench.py --steps 3 --warmup 1 > "$OUT/bench_1gpu.json.log" 2> "$OUT/bench_1gpu.stderr"
