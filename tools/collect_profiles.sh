@@ -17,6 +17,7 @@ cd "$ROOT"
 TRACE=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
 STATS=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
 python tools/prof_summary.py "$TRACE" "$OUT/ops.txt" > "$OUT/kernel_trace_summary.txt"
+python tools/kernel_table.py "$TRACE" "$OUT/ops.txt" > "$OUT/kernel_table.txt"
 cp "$STATS" "$OUT/kernel_stats.csv"
 rm -f "$TRACE"                                     # tens of MB; the summary and stats are what is kept
 grep "steps x" "$OUT/kernel_trace_summary.txt"
@@ -53,4 +54,5 @@ PY
 timeout -k 10 600 python bench.py --steps 3 --warmup 1 > "$OUT/bench_1gpu.json.log" 2> "$OUT/bench_1gpu.stderr"
 tail -c 600 "$OUT/bench_1gpu.json.log"; echo
 
+cp "$ROOT/profiles/${R}_traffic.json" "$ROOT/profiles/traffic_latest.json" "$OUT/" 2>/dev/null || true   # profiles/ does not travel back: gpurun_out/ does
 echo done
