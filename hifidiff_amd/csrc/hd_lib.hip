@@ -96,9 +96,11 @@ struct Chain {
     hipStream_t stream = nullptr;            // the chain's own queue for the sampling loop
     hipEvent_t done = nullptr;
     hipGraphExec_t graph_exec = nullptr;     // program + scheduler update of this chain, replayed per step
+    hipGraphExec_t graph_multi = nullptr;    // kGraphSteps consecutive steps in one graph (the step index lives in device memory)
 };
 
 static std::string g_create_error;
+constexpr int kGraphSteps = 10;              // diffusion steps per captured graph in hd_sample (plus a one-step graph for the remainder)
 
 // Everything whose size depends on the batch: buffers, launch programs, captured graphs.  One context serves any batch
 // size (the reference's val loop has a ragged last batch: DataLoader without drop_last, test_refiner.py:160): the
@@ -263,6 +265,7 @@ constexpr size_t kWsCached = 3;
 void destroy_saved(SavedWs& w) {
     for (auto& ch : w.chains) {
         if (ch.graph_exec) (void)hipGraphExecDestroy(ch.graph_exec);
+        if (ch.graph_multi) (void)hipGraphExecDestroy(ch.graph_multi);
         if (ch.stream) (void)hipStreamDestroy(ch.stream);
         if (ch.done) (void)hipEventDestroy(ch.done);
     }
@@ -1902,6 +1905,7 @@ void hd_destroy(hd_ctx* c) {
     (void)hipDeviceSynchronize();
     for (auto& ch : c->chains) {
         if (ch.graph_exec) (void)hipGraphExecDestroy(ch.graph_exec);
+        if (ch.graph_multi) (void)hipGraphExecDestroy(ch.graph_multi);
         if (ch.stream) (void)hipStreamDestroy(ch.stream);
         if (ch.done) (void)hipEventDestroy(ch.done);
     }
@@ -2361,24 +2365,33 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
         // chains are independent over the whole loop and each graph is replayed on the chain's own stream.
         for (auto& ch : c->chains) {
             if (ch.graph_exec) { (void)hipGraphExecDestroy(ch.graph_exec); ch.graph_exec = nullptr; }
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(ch.stream, hipStreamCaptureModeThreadLocal);
-            if (e == hipSuccess) {
-                for (size_t k = 0; k < ch.program.size() && e == hipSuccess; ++k) e = ch.program[k].run(ch.stream);
-                hipError_t e2 = hipStreamEndCapture(ch.stream, &graph);
-                if (e == hipSuccess) e = e2;
+            if (ch.graph_multi) { (void)hipGraphExecDestroy(ch.graph_multi); ch.graph_multi = nullptr; }
+            for (int multi = 0; multi < 2; ++multi) {       // one step, and kGraphSteps steps back to back (fewer graph launches)
+                hipGraph_t graph = nullptr;
+                hipError_t e = hipStreamBeginCapture(ch.stream, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    for (int r = 0; r < (multi ? kGraphSteps : 1) && e == hipSuccess; ++r)
+                        for (size_t k = 0; k < ch.program.size() && e == hipSuccess; ++k) e = ch.program[k].run(ch.stream);
+                    hipError_t e2 = hipStreamEndCapture(ch.stream, &graph);
+                    if (e == hipSuccess) e = e2;
+                }
+                if (e == hipSuccess) e = hipGraphInstantiate(multi ? &ch.graph_multi : &ch.graph_exec, graph, nullptr, nullptr, 0);
+                if (graph) (void)hipGraphDestroy(graph);
+                if (e != hipSuccess) HD_FAIL(c, HD_ERR_HIP, "graph capture/instantiate failed: %s", hipGetErrorString(e));
             }
-            if (e == hipSuccess) e = hipGraphInstantiate(&ch.graph_exec, graph, nullptr, nullptr, 0);
-            if (graph) (void)hipGraphDestroy(graph);
-            if (e != hipSuccess) HD_FAIL(c, HD_ERR_HIP, "graph capture/instantiate failed: %s", hipGetErrorString(e));
         }
         c->graphs_valid = true; c->graph_film = c->film_table; c->graph_B = c->B;
     }
     if (c->profiling) HIPCHECK(c, hipEventRecord(c->ev0, s));
     HIPCHECK(c, hipEventRecord(c->fork_ev, s));
     for (auto& ch : c->chains) HIPCHECK(c, hipStreamWaitEvent(ch.stream, c->fork_ev, 0));
-    for (int i = 0; i < n; ++i)
-        for (auto& ch : c->chains) HIPCHECK(c, hipGraphLaunch(ch.graph_exec, ch.stream));
+    {
+        int i = 0;
+        for (; i + kGraphSteps <= n; i += kGraphSteps)
+            for (auto& ch : c->chains) HIPCHECK(c, hipGraphLaunch(ch.graph_multi, ch.stream));
+        for (; i < n; ++i)
+            for (auto& ch : c->chains) HIPCHECK(c, hipGraphLaunch(ch.graph_exec, ch.stream));
+    }
     for (auto& ch : c->chains) {
         HIPCHECK(c, hipEventRecord(ch.done, ch.stream));
         HIPCHECK(c, hipStreamWaitEvent(s, ch.done, 0));
