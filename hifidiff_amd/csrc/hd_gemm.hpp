@@ -29,7 +29,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 namespace hd {
+
+// Tile-shape and fusion rules are FIXED in the product.  The HD_* experiment switches that were used to measure them
+//  are read only when HD_EXPERIMENTS=1 is set; otherwise they are inert.  Run-time options that stay:
+// HD_CHAINS (independent sub-batches), HD_TAIL / HD_NO_TAIL (the persistent middle-level kernel).
+inline const char* hd_env(const char* name) {
+    static const bool on = getenv("HD_EXPERIMENTS") != nullptr;
+    return on ? getenv(name) : nullptr;
+}
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -362,12 +372,27 @@ struct LdF32LN {
         if (!(st.valid && kc + 8 * kq < p.K)) return make_uint4(0, 0, 0, 0);
         unpack8(r.x, v);
         const int k = kc + 8 * kq;
-        const float* gp = st.gbl ? st.gbl + k : st.gain + k;
-        const float* bp = st.gbl ? st.gbl + p.Kp + k : st.bias + k;
-        F8 gg, bb;
-        gg.a = *reinterpret_cast<const float4*>(gp); gg.b = *reinterpret_cast<const float4*>(gp + 4);
-        bb.a = *reinterpret_cast<const float4*>(bp); bb.b = *reinterpret_cast<const float4*>(bp + 4);
-        f8_to_arr(gg, g); f8_to_arr(bb, b);
+        // The address space of each source is spelled out: a pointer selected at run time between the LDS copy and the global
+        // table is a generic pointer to the compiler, i.e. flat loads, and a flat load is followed by s_waitcnt vmcnt(0)
+        // lgkmcnt(0) -- which drained every weight / A prefetch in flight in EVERY chunk of the K loop (measured: 2.6-4.1 us
+        // per LayerNorm GEMM against the same GEMM with the plain loader, tools/gemm_bench).
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v g0, g1, b0, b1;
+        if (st.gbl) {                                                 // shared FiLM row, copied to LDS by block_finish (wave-uniform)
+            typedef __attribute__((address_space(3))) const f4v lds_f4;
+            typedef __attribute__((address_space(3))) const float lds_f1;
+            lds_f1* gl = (lds_f1*)st.gbl;
+            g0 = *(lds_f4*)(gl + k); g1 = *(lds_f4*)(gl + k + 4);
+            b0 = *(lds_f4*)(gl + p.Kp + k); b1 = *(lds_f4*)(gl + p.Kp + k + 4);
+        } else {                                                      // per-face timesteps: rows of the global table
+            typedef __attribute__((address_space(1))) const f4v gl_f4;
+            typedef __attribute__((address_space(1))) const float gl_f1;
+            gl_f1 *gg = (gl_f1*)st.gain, *bg = (gl_f1*)st.bias;
+            g0 = *(gl_f4*)(gg + k); g1 = *(gl_f4*)(gg + k + 4);
+            b0 = *(gl_f4*)(bg + k); b1 = *(gl_f4*)(bg + k + 4);
+        }
+        g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaf(fmaf(v[i], st.rstd, st.mu), g[i], b[i]);
         return pack8(v);
@@ -1350,10 +1375,10 @@ inline hipError_t launch_skinny_auto(const GemmP& p, hipStream_t s) {
     const int chunks = p.Kp / 64;
     if constexpr (WM == 1 && MT == 1) {
         // few rows, many columns: 16-row tiles double the workgroups so that every CU streams weights
-        static const bool no_half = getenv("HD_NO_HALF") != nullptr;
+        static const bool no_half = hd_env("HD_NO_HALF") != nullptr;
         const int tiles = (PAIR ? p.N / 2 : p.N) / 32;
-        static const int half_m = getenv("HD_HALF_M") ? atoi(getenv("HD_HALF_M")) : 64;
-        static const int half_wg = getenv("HD_HALF_WG") ? atoi(getenv("HD_HALF_WG")) : 256;
+        static const int half_m = hd_env("HD_HALF_M") ? atoi(hd_env("HD_HALF_M")) : 64;
+        static const int half_wg = hd_env("HD_HALF_WG") ? atoi(hd_env("HD_HALF_WG")) : 256;
         if (!no_half && p.M <= half_m && p.M % 16 == 0 && ((p.M + 31) / 32) * tiles < half_wg) {
             if (chunks >= 16 && chunks % 8 == 0) return launch_skinny<SkinnyCfg<1, 8, 1, PAIR, D, true>, LD, EP>(p, s);
             if (chunks >= 8 && chunks % 4 == 0) return launch_skinny<SkinnyCfg<1, 4, 1, PAIR, D, true>, LD, EP>(p, s);

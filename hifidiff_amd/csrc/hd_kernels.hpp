@@ -142,7 +142,8 @@ __device__ __forceinline__ float sched_update(float xv, float e, const float* c,
     x0 = fminf(fmaxf(x0, -c[2]), c[2]);
     float r = c[3] * x0 + c[4] * xv + c[5] * e;
     if (c[6] != 0.f) {
-        const float z = st->noise ? st->noise[(size_t)step * n_total + gi] : philox_normal(st->seed, (unsigned)step, (unsigned)gi);
+        // (the pointer is read from device memory: say that it is a global pointer, or the load is a flat load with a full wait)
+        const float z = st->noise ? ((const __attribute__((address_space(1))) float*)st->noise)[(size_t)step * n_total + gi] : philox_normal(st->seed, (unsigned)step, (unsigned)gi);
         r += c[6] * z;
     }
     return r;

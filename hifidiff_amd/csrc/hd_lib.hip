@@ -552,7 +552,7 @@ hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
     // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle)
     if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate>(p, s);
-    static const bool big64 = getenv("HD_NO_DW64_WM8") == nullptr;      // 256-row tiles (4 faces of 8x8) when 64-row tiles would put >= 4 workgroups on a CU
+    static const bool big64 = hd_env("HD_NO_DW64_WM8") == nullptr;      // 256-row tiles (4 faces of 8x8) when 64-row tiles would put >= 4 workgroups on a CU
     if (p.hw == 64 && big64 && p.M % 256 == 0 && (p.M / 64) * (p.N / 64) >= 1024) return launch_skinny_auto<8, 1, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw == 64) return launch_skinny_auto<2, 1, true, LdF32LN, EpDwGate>(p, s);
     if (p.hw == 256) return launch_skinny_auto<8, 1, true, LdF32LN, EpDwGate>(p, s);
@@ -562,7 +562,7 @@ bool dwgate_ok(int hw) { return hw == 1 || hw == 4 || hw == 16 || hw == 64 || hw
 
 hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStream_t s) {
     if (lk == LK_LN && ek == EK_DWGATE) {
-        static const bool no_dw1 = getenv("HD_NO_DW1") != nullptr;
+        static const bool no_dw1 = hd_env("HD_NO_DW1") != nullptr;
         if (p.hw == 1 && !no_dw1) return launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate1>(p, s);   // one pixel per face: element-wise
         return dispatch_dwgate(p, s);
     }
@@ -576,7 +576,7 @@ hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStre
     if (lk == LK_CONV_BF16 && ek == EK_BIASF32) return launch_tile<LdConv<true, false>, EpBiasF32, false>(p, mode, s);
     if (lk == LK_BF16 && ek == EK_PIXSHUF) return launch_tile<LdBF16Plain, EpPixShufF32, false>(p, mode, s);
     if (lk == LK_BF16 && ek == EK_SCA) {
-        static const bool no_dw1 = getenv("HD_NO_DW1") != nullptr;
+        static const bool no_dw1 = hd_env("HD_NO_DW1") != nullptr;
         if (p.scale_hw == 1 && !no_dw1) return launch_skinny_auto<1, 1, false, LdBF16Plain, EpSca1BF16>(p, s);
         return launch_skinny_auto<1, 1, false, LdBF16Plain, EpScaBF16>(p, s);   // its in-place G scaling is a skinny tile epilogue
     }
@@ -592,7 +592,7 @@ hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStre
 int choose_mode(const GemmP& p, bool pair) {
     const int ncols = pair ? p.N / 2 : p.N;
     const int nb64 = (ncols + 63) / 64, nb32 = (ncols + 31) / 32;
-    static const int force = getenv("HD_GEMM_MODE") ? atoi(getenv("HD_GEMM_MODE")) : -1;
+    static const int force = hd_env("HD_GEMM_MODE") ? atoi(hd_env("HD_GEMM_MODE")) : -1;
     if (force >= 0) return force;
     const int nb256 = (ncols + (pair ? 127 : 255)) / (pair ? 128 : 256);
     if (p.Kp <= 256 && nb256 <= 2 && ((p.M + 31) / 32) * nb256 >= 512) return 4;   // levels 0/1 at full batch
@@ -603,7 +603,7 @@ int choose_mode(const GemmP& p, bool pair) {
         if (((p.M + 255) / 256) * nb32 >= 256) return 6;
         if (((p.M + 127) / 128) * nb32 >= 192) return 5;
     }
-    static const int tall_maxk = getenv("HD_TALL_MAXK") ? atoi(getenv("HD_TALL_MAXK")) : 128;   // the tall kernel prefetches one chunk ahead only: with more than two K chunks the skinny kernel (whole K slice in flight) wins even at large M (measured)
+    static const int tall_maxk = hd_env("HD_TALL_MAXK") ? atoi(hd_env("HD_TALL_MAXK")) : 128;   // the tall kernel prefetches one chunk ahead only: with more than two K chunks the skinny kernel (whole K slice in flight) wins even at large M (measured)
     if (p.Kp <= tall_maxk) {
         if (((p.M + 127) / 128) * nb64 >= 256) return 0;
         if (((p.M + 63) / 64) * nb64 >= 256) return 1;
@@ -627,8 +627,8 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
     {   // each XCD re-fetches what its workgroups read: share the bigger operand through the XCD's L2
         const size_t a_bytes = (size_t)p.M * p.Kp * ((lk == LK_BF16 || lk == LK_BF16S || lk == LK_CONV_BF16 || lk == LK_LN) ? 2 : 4);
         p.xcd_tile_affine = ((size_t)p.N * p.Kp * 2 > a_bytes) ? 1 : 0;
-        static const bool no_nt = getenv("HD_NO_NT") != nullptr;
-        static const int nt_maxm = getenv("HD_NT_MAXM") ? atoi(getenv("HD_NT_MAXM")) : 256;
+        static const bool no_nt = hd_env("HD_NO_NT") != nullptr;
+        static const int nt_maxm = hd_env("HD_NT_MAXM") ? atoi(hd_env("HD_NT_MAXM")) : 256;
         p.w_nt = (!no_nt && p.xcd_tile_affine && p.M <= nt_maxm) ? 1 : 0;     // <= 8 row groups share a weight tile
     }
     const bool film = (lk == LK_LN);
@@ -669,7 +669,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         p.film_gain_off = bw.film_off + (2 * half + 1) * C;
         p.film_face_stride = 0; p.film_step_stride = 0; p.step_ptr = nullptr;
     };
-    static const bool no_fuse = getenv("HD_NO_DWFUSE") != nullptr;
+    static const bool no_fuse = hd_env("HD_NO_DWFUSE") != nullptr;
     if (dwgate_ok(HW) && !no_fuse) {
         // LN1 + FiLM -> conv1 (+bias) -> depthwise 3x3 -> SimpleGate -> G, pooled mean: one launch
         GemmP p = base_gemm(bw.conv1, M);
@@ -704,7 +704,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
             prog.back().out = pooled; prog.back().out_elems = (size_t)faces * C;
         }
     }
-    static const bool no_chain = getenv("HD_NO_CHAIN") != nullptr;
+    static const bool no_chain = hd_env("HD_NO_CHAIN") != nullptr;
     if ((C == 128 || C == 256) && HW % 32 == 0 && !no_fuse && !no_chain) {        // also behind the unfused depthwise path (latent 32, level 0)
         // levels 0/1: sca -> conv3 -> residual -> LN+FiLM -> conv4 -> gate -> conv5 -> residual in ONE launch (hd_chain.hpp)
         ChainP q{};
@@ -719,7 +719,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         const bool big = (C == 256);
         // 64-row workgroups at level 0 halve the weight re-reads but leave one 4-wave workgroup per CU with nothing to
         // overlap its barrier-separated phases with: measured 21.4 us against 16.8 us for 32-row tiles (two per CU) -> opt-in
-        static const int mt128 = getenv("HD_CHAIN_MT") ? atoi(getenv("HD_CHAIN_MT")) : 1;
+        static const int mt128 = hd_env("HD_CHAIN_MT") ? atoi(hd_env("HD_CHAIN_MT")) : 1;
         const bool two = !big && mt128 == 2 && HW % 64 == 0 && M % 64 == 0;
         Op op;
         op.name = bw.name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)M * C; op.out_bf16 = 0;
@@ -812,7 +812,7 @@ void add_up(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Pac
 // plain bf16 implicit GEMM; BN folded, ReLU; fp32 output (+ bf16 copy for the up-conv that follows).
 void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const HcaW& hw, const unsigned short* in, float* out,
              unsigned short* out16, int M, int H) {
-    static const bool no_lds = getenv("HD_NO_CONVLDS") != nullptr;
+    static const bool no_lds = hd_env("HD_NO_CONVLDS") != nullptr;
     if (!hw.centre_only && !no_lds) {
         // faces small enough to sit in LDS: the A operand is built from the staged faces (hd_conv.hpp)
         ConvP q{};
@@ -854,9 +854,9 @@ void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Hc
 // consumers get 0.5-1 us faster (L2-latency instead of HBM-latency ingest) but the producers, themselves ingest
 // bound with no idle memory phase, slow down by more (1592 -> 1633 us/step), so it is OFF unless HD_PREFETCH is set.
 void link_prefetch(std::vector<Op>& prog, bool wrap) {
-    static const bool off = getenv("HD_PREFETCH") == nullptr;
-    static const std::string only = getenv("HD_PREFETCH") ? getenv("HD_PREFETCH") : "";   // "1": every GEMM; else producer-name suffix
-    static const size_t min_bytes = getenv("HD_PF_MIN") ? (size_t)atol(getenv("HD_PF_MIN")) : (size_t)1 << 20;
+    static const bool off = hd_env("HD_PREFETCH") == nullptr;
+    static const std::string only = hd_env("HD_PREFETCH") ? hd_env("HD_PREFETCH") : "";   // "1": every GEMM; else producer-name suffix
+    static const size_t min_bytes = hd_env("HD_PF_MIN") ? (size_t)atol(hd_env("HD_PF_MIN")) : (size_t)1 << 20;
     const int n = (int)prog.size();
     for (int i = 0; i < n; ++i) {
         if (!prog[i].gemm) continue;

@@ -174,6 +174,16 @@ int main(int argc, char** argv) {
         RUN_SK("skinny LN bias MT1 W8 D4", 1, 8, false, 4, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
         RUN_SK("skinny LN gate(pair) MT1 W8 D2", 1, 8, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SK("skinny LN gate(pair) MT2 W8 D1", 2, 8, true, 1, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny bf16plain gate(pair) MT1 W8 D2 (no LN)", 1, 8, true, 2, LdBF16Plain, EpGateBF16, (p.A = Ab, p.lda = LDA, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny bf16plain bias MT1 W8 D2 (no LN)", 1, 8, false, 2, LdBF16Plain, EpBiasF32, (p.A = Ab, p.lda = LDA))
+        // four waves per workgroup (one per SIMD: up to 512 VGPRs each): the whole K slice of a wave in flight
+        RUN_SK("skinny LN gate(pair) MT2 W4 D2", 2, 4, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny LN gate(pair) MT2 W4 D3", 2, 4, true, 3, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny LN gate(pair) MT2 W4 D4", 2, 4, true, 4, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny LN gate(pair) MT1 W4 D4", 1, 4, true, 4, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny LN gate(pair) MT1 W8 D3", 1, 8, true, 3, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny bf16plain resid MT2 W4 D4", 2, 4, false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
+        RUN_SK("skinny bf16plain resid MT2 W4 D3", 2, 4, false, 3, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
     }
 #define RUN_TALL(name, CFG, LD, EP, setup)                                                               \
     {                                                                                                    \
