@@ -188,7 +188,7 @@ __device__ __forceinline__ void lds_write_unit(char* row_base, int kq, uint4 v) 
 // fp32 rows, optional scalar scale (SCA pooled input, up-conv input, gate MLPs)
 struct LdF32Plain {
     static constexpr int kRawRegs = 8;
-    static constexpr bool kGainBiasLds = false, kSplit = true;
+    static constexpr bool kGainBiasLds = false, kSplit = true, kStaticK = false;
     struct St { const float* rowp; bool valid; };
     struct Raw { F8 x; };
     struct Pre {};
@@ -217,9 +217,16 @@ struct LdF32Plain {
 // utils.py:18-22) -> folded LN-affine/FiLM gain and bias (conditional_naf.py:114-115,126-127).  The row
 // statistics are exact fp32 (producer partials of the unrounded values); only the value being normalised
 // is the bf16 copy, which halves the bytes every workgroup ingests.
-struct LdF32LN {
+// PER_FACE is a compile-time property of the kernel: false = every face shares one FiLM row, copied to LDS once per
+// workgroup (the sampling loop, scalar timesteps); true = per-face timesteps, gain / bias read from the rows of the global
+// table.  A run-time choice between the two sources inside finish() costs the whole K loop its prefetch depth: the pointer
+// becomes generic (flat loads + s_waitcnt vmcnt(0) lgkmcnt(0)), and with two typed branches the wait for the global branch
+// still lands after the join -- every weight / A load in flight was drained in every chunk (tools/gemm_bench: the LayerNorm
+// GEMMs cost 2.6-4.1 us more than the same GEMM with the plain loader).
+template <bool PER_FACE>
+struct LdF32LN_T {
     static constexpr int kRawRegs = 4;
-    static constexpr bool kGainBiasLds = true, kSplit = false;
+    static constexpr bool kGainBiasLds = !PER_FACE, kSplit = false, kStaticK = true;
     struct St { const unsigned short* rowp; const float* gain; const float* bias; const float* gbl; float mu, rstd; bool valid; };   // mu holds -mean*rstd
     struct Raw { uint4 x; };
     // block prologue in two halves so that its (small) loads can be issued before the weight / A streams and
@@ -367,24 +374,25 @@ struct LdF32LN {
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
         r.x = (st.valid && kc + 8 * kq < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
     }
+    // K % 64 == 0 (host): no bound to test, the load is not under a branch (rows beyond M re-read row 0 and are zeroed by
+    // finish()), so the compiler can count the loads in flight (see gemm_skinny_kernel, CPW)
+    static __device__ __forceinline__ void fetch_nc(const St& st, int kc, int kq, Raw& r) {
+        r.x = *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq);
+    }
     static __device__ __forceinline__ uint4 finish(const GemmP& p, const St& st, int kc, int kq, const Raw& r) {
         float v[8], g[8], b[8];
         if (!(st.valid && kc + 8 * kq < p.K)) return make_uint4(0, 0, 0, 0);
         unpack8(r.x, v);
         const int k = kc + 8 * kq;
-        // The address space of each source is spelled out: a pointer selected at run time between the LDS copy and the global
-        // table is a generic pointer to the compiler, i.e. flat loads, and a flat load is followed by s_waitcnt vmcnt(0)
-        // lgkmcnt(0) -- which drained every weight / A prefetch in flight in EVERY chunk of the K loop (measured: 2.6-4.1 us
-        // per LayerNorm GEMM against the same GEMM with the plain loader, tools/gemm_bench).
         typedef float f4v __attribute__((ext_vector_type(4)));
         f4v g0, g1, b0, b1;
-        if (st.gbl) {                                                 // shared FiLM row, copied to LDS by block_finish (wave-uniform)
+        if constexpr (!PER_FACE) {                                    // shared FiLM row in LDS (block_finish)
             typedef __attribute__((address_space(3))) const f4v lds_f4;
             typedef __attribute__((address_space(3))) const float lds_f1;
             lds_f1* gl = (lds_f1*)st.gbl;
             g0 = *(lds_f4*)(gl + k); g1 = *(lds_f4*)(gl + k + 4);
             b0 = *(lds_f4*)(gl + p.Kp + k); b1 = *(lds_f4*)(gl + p.Kp + k + 4);
-        } else {                                                      // per-face timesteps: rows of the global table
+        } else {                                                      // rows of the global table
             typedef __attribute__((address_space(1))) const f4v gl_f4;
             typedef __attribute__((address_space(1))) const float gl_f1;
             gl_f1 *gg = (gl_f1*)st.gain, *bg = (gl_f1*)st.bias;
@@ -399,10 +407,13 @@ struct LdF32LN {
     }
 };
 
+typedef LdF32LN_T<false> LdF32LN;          // one FiLM row for all faces
+typedef LdF32LN_T<true> LdF32LNFace;       // per-face timesteps
+
 // bf16 rows, copied as they are (conv5 input G2, ResNet 1x1 convs)
 struct LdBF16Plain {
     static constexpr int kRawRegs = 4;
-    static constexpr bool kGainBiasLds = false, kSplit = false;
+    static constexpr bool kGainBiasLds = false, kSplit = false, kStaticK = true;
     struct St { const unsigned short* rowp; bool valid; };
     struct Raw { uint4 x; };
     struct Pre {};
@@ -417,13 +428,18 @@ struct LdBF16Plain {
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
         r.x = (st.valid && kc + 8 * kq < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
     }
-    static __device__ __forceinline__ uint4 finish(const GemmP&, const St&, int, int, const Raw& r) { return r.x; }
+    static __device__ __forceinline__ void fetch_nc(const St& st, int kc, int kq, Raw& r) {
+        r.x = *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq);
+    }
+    static __device__ __forceinline__ uint4 finish(const GemmP&, const St& st, int, int, const Raw& r) {
+        return st.valid ? r.x : make_uint4(0, 0, 0, 0);
+    }
 };
 
 // bf16 rows times a per-(face, k) fp32 scale: x * sca(x) feeding conv3 (conditional_naf.py:119-120)
 struct LdBF16Scale {
     static constexpr int kRawRegs = 12;
-    static constexpr bool kGainBiasLds = false, kSplit = false;
+    static constexpr bool kGainBiasLds = false, kSplit = false, kStaticK = false;
     struct St { const unsigned short* rowp; const float* srow; bool valid; };
     struct Raw { uint4 x; F8 s; };
     struct Pre {};
@@ -459,7 +475,7 @@ struct LdBF16Scale {
 template <bool SRC_BF16, bool GATED>
 struct LdConv {
     static constexpr int kRawRegs = (SRC_BF16 ? 4 : 8) + (GATED ? 18 : 0) + 2;
-    static constexpr bool kGainBiasLds = false, kSplit = !SRC_BF16;
+    static constexpr bool kGainBiasLds = false, kSplit = !SRC_BF16, kStaticK = false;
     struct St { int b, iy0, ix0; bool valid; };
     struct Raw { float4 x[2]; float4 add[2]; float4 gc[2]; float gs[2]; uint4 xb; bool inb[2]; };
     struct Pre {};
@@ -1023,7 +1039,12 @@ __device__ __forceinline__ void skinny_rows_epilogue(const GemmP& p, const float
     }
 }
 
-template <class C, class LD, class EP, bool W_NT = false>
+// CPW > 0: the number of 64-deep chunks per wave is a compile-time constant (host: Kp / 64 / WK == CPW, K == Kp) and the
+// K loop is straight-line code whose loads are not under any branch.  With a run-time trip count every prefetch sits
+// behind a bounds test, the compiler can then no longer tell how many loads are in flight at the top of a chunk and
+// drains all of them (s_waitcnt vmcnt(0)): each chunk waits for the prefetch issued one chunk earlier, i.e. a full
+// memory round trip per chunk instead of D chunks in flight.
+template <class C, class LD, class EP, bool W_NT = false, int CPW = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = C::MT, TNT = C::TNT, WK = C::WK, D = C::D, UN = C::UN;
@@ -1042,7 +1063,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     }
     const int row0 = bx * C::BM;
     const int ksteps_total = p.Kp >> 4;
-    const int cpw = (p.Kp >> 6) / WK;                        // host: Kp % (64*WK) == 0
+    const int cpw = CPW > 0 ? CPW : (p.Kp >> 6) / WK;        // host: Kp % (64*WK) == 0
     const int c0 = wk * cpw, c_end = c0 + cpw;
     int tile[TNT];
     tile[0] = by;
@@ -1072,8 +1093,13 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + C::GB_OFF) : nullptr;
     typename LD::Pre pre;
     LD::template block_issue<C::BM, C::THREADS>(p, row0, gb, tid, pre);
+#define HD_SK_LOAD_B_NC(slot, chunk)                                                                   \
+    _Pragma("unroll") for (int ss = 0; ss < 4; ++ss) _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn) \
+        bq[slot][ss][tn] = w_nt ? nt_load_u4(&Wl[((size_t)tile[tn] * ksteps_total + (chunk) * 4 + ss) * 64]) : Wl[((size_t)tile[tn] * ksteps_total + (chunk) * 4 + ss) * 64];
+    if constexpr (CPW == 0) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) { HD_SK_LOAD_B(d, c0 + d); }
+        for (int d = 0; d < D; ++d) { HD_SK_LOAD_B(d, c0 + d); }
+    }
 
     typename LD::St st[UN];
     int u_off[UN];
@@ -1090,8 +1116,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
 #define HD_SK_FETCH_A(slot, chunk)                                                                     \
     _Pragma("unroll") for (int u = 0; u < UN; ++u)                                                     \
         LD::fetch(p, st[u], ((chunk) < c_end) ? (chunk) * BK : p.Kp, kq, aq[slot][u]);
+#define HD_SK_FETCH_A_NC(slot, chunk) \
+    _Pragma("unroll") for (int u = 0; u < UN; ++u) LD::fetch_nc(st[u], (chunk) * BK, kq, aq[slot][u]);
+    if constexpr (CPW > 0) {                                   // chunk by chunk: loads return in issue order, chunk 0 is needed first
 #pragma unroll
-    for (int d = 0; d < D; ++d) { HD_SK_FETCH_A(d, c0 + d); }
+        for (int d = 0; d < (D < CPW ? D : CPW); ++d) { HD_SK_LOAD_B_NC(d, c0 + d); HD_SK_FETCH_A_NC(d, c0 + d); }
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) { HD_SK_FETCH_A(d, c0 + d); }
+    }
     // fused depthwise epilogue: its per-channel weights (tap-major copy: coalesced) are requested now, not after the
     // K loop (a dependent global round trip inside the epilogue otherwise)
     // (only in the 8-wave shapes: in the 4-wave shapes, two workgroups per CU, the extra live registers cost more)
@@ -1142,37 +1175,52 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         for (int i = lane; i < 16 * LDS_ROW / 16; i += 64) reinterpret_cast<uint4*>(sA + 16 * LDS_ROW)[i] = make_uint4(0, 0, 0, 0);
         __builtin_amdgcn_wave_barrier();
     }
-    for (int cb = c0; cb < c_end; cb += D) {
+    auto chunk_mma = [&](int d, int cc) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int cc = cb + d;
-            if (cc < c_end) {                                      // wave-uniform
+        for (int u = 0; u < UN; ++u)
+            lds_write_unit<LD::kSplit>(sA + u_off[u], kq, LD::finish(p, st[u], cc * BK, kq, aq[d][u]));
+        __builtin_amdgcn_wave_barrier();                           // LDS ops of one wave execute in order
 #pragma unroll
-                for (int u = 0; u < UN; ++u)
-                    lds_write_unit<LD::kSplit>(sA + u_off[u], kq, LD::finish(p, st[u], cc * BK, kq, aq[d][u]));
-                __builtin_amdgcn_wave_barrier();                   // LDS ops of one wave execute in order
+        for (int ss = 0; ss < 4; ++ss) {
+            bf16x8_t a[MT];
 #pragma unroll
-                for (int ss = 0; ss < 4; ++ss) {
-                    bf16x8_t a[MT];
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const bf16x8_t*>(sA + a_lane_off + (mt * 32) * LDS_ROW + ss * 32);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        a[mt] = *reinterpret_cast<const bf16x8_t*>(sA + a_lane_off + (mt * 32) * LDS_ROW + ss * 32);
+            for (int tn = 0; tn < TNT; ++tn)
 #pragma unroll
-                    for (int tn = 0; tn < TNT; ++tn)
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        a[mt], __builtin_bit_cast(bf16x8_t, bq[d][ss][tn]), acc[mt][tn], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    if constexpr (CPW > 0) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[mt][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                a[mt], __builtin_bit_cast(bf16x8_t, bq[d][ss][tn]), acc[mt][tn], 0, 0, 0);
+        for (int i = 0; i < CPW; ++i) {
+            const int d = i % D, cc = c0 + i;
+            chunk_mma(d, cc);
+            if (i + D < CPW) { HD_SK_LOAD_B_NC(d, cc + D); HD_SK_FETCH_A_NC(d, cc + D); }
+            if (i == 0) HD_STAMP(2);
+        }
+    } else {
+        for (int cb = c0; cb < c_end; cb += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int cc = cb + d;
+                if (cc < c_end) {                                  // wave-uniform
+                    chunk_mma(d, cc);
+                    HD_SK_LOAD_B(d, cc + D);
+                    HD_SK_FETCH_A(d, cc + D);
+                    if (cc == c0) HD_STAMP(2);
                 }
-                __builtin_amdgcn_wave_barrier();
-                HD_SK_LOAD_B(d, cc + D);
-                HD_SK_FETCH_A(d, cc + D);
-                if (cc == c0) HD_STAMP(2);
             }
         }
     }
 #undef HD_SK_LOAD_B
 #undef HD_SK_FETCH_A
+#undef HD_SK_LOAD_B_NC
+#undef HD_SK_FETCH_A_NC
     HD_STAMP(3);
 
     // ---- partial tiles to LDS: red[wk][tn][row in BM][32] ----
@@ -1337,25 +1385,39 @@ inline hipError_t launch_gemm(const GemmP& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <class C, class LD, class EP, bool NT, int CPW>
+inline hipError_t launch_skinny_inst(const GemmP& p, hipStream_t s, int smem) {
+    if (smem > 65536) {
+        static bool granted = false;
+        if (!granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP, NT, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            granted = true;
+        }
+    }
+    const int ncols = (C::TNT == 2) ? p.N / 2 : p.N;
+    dim3 grid((p.M + C::BM - 1) / C::BM, (ncols + 31) / 32, 1);
+    hipLaunchKernelGGL((gemm_skinny_kernel<C, LD, EP, NT, CPW>), grid, dim3(C::THREADS), smem, s, p);
+    return hipGetLastError();
+}
+
 template <class C, class LD, class EP>
 inline hipError_t launch_skinny(const GemmP& p, hipStream_t s) {
     const int smem = C::GB_OFF + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0);
     if (smem > 160 * 1024 || (p.Kp / 64) % C::WK != 0) return hipErrorInvalidValue;
     const bool nt = p.w_nt != 0;
-    if (smem > 65536) {
-        static bool granted[2] = {false, false};
-        if (!granted[nt]) {
-            hipError_t e = nt ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                              : hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            granted[nt] = true;
+    // the hot shapes (K split over 8 waves, 2 or 4 chunks each, K a multiple of 64, whole weight tiles) get the
+    // straight-line K loop (gemm_skinny_kernel, CPW)
+    if constexpr (LD::kStaticK && C::WK == 8) {
+        static const bool no_static = hd_env("HD_NO_STATIC_K") != nullptr;
+        const int cpw = (p.Kp / 64) / C::WK;
+        const int ncols = (C::TNT == 2) ? p.N / 2 : p.N;
+        if (!no_static && p.K == p.Kp && ncols % 32 == 0 && (cpw == 2 || cpw == 4)) {
+            if (cpw == 4) return nt ? launch_skinny_inst<C, LD, EP, true, 4>(p, s, smem) : launch_skinny_inst<C, LD, EP, false, 4>(p, s, smem);
+            return nt ? launch_skinny_inst<C, LD, EP, true, 2>(p, s, smem) : launch_skinny_inst<C, LD, EP, false, 2>(p, s, smem);
         }
     }
-    const int ncols = (C::TNT == 2) ? p.N / 2 : p.N;
-    dim3 grid((p.M + C::BM - 1) / C::BM, (ncols + 31) / 32, 1);
-    if (nt) hipLaunchKernelGGL((gemm_skinny_kernel<C, LD, EP, true>), grid, dim3(C::THREADS), smem, s, p);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<C, LD, EP, false>), grid, dim3(C::THREADS), smem, s, p);
-    return hipGetLastError();
+    return nt ? launch_skinny_inst<C, LD, EP, true, 0>(p, s, smem) : launch_skinny_inst<C, LD, EP, false, 0>(p, s, smem);
 }
 
 // Chunks in flight per wave from a register budget: accumulators + D x (B fragments + raw A units) must

@@ -548,26 +548,31 @@ hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
 }
 
 // conv1 with the depthwise 3x3 + SimpleGate + pool fused: workgroup = whole faces (BM = max(32, hw) rows)
+template <class LN>
 hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
     // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle)
-    if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LdF32LN, EpDwGate>(p, s);
-    if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate>(p, s);
+    if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LN, EpDwGate>(p, s);
+    if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LN, EpDwGate>(p, s);
     static const bool big64 = hd_env("HD_NO_DW64_WM8") == nullptr;      // 256-row tiles (4 faces of 8x8) when 64-row tiles would put >= 4 workgroups on a CU
-    if (p.hw == 64 && big64 && p.M % 256 == 0 && (p.M / 64) * (p.N / 64) >= 1024) return launch_skinny_auto<8, 1, true, LdF32LN, EpDwGate>(p, s);
-    if (p.hw == 64) return launch_skinny_auto<2, 1, true, LdF32LN, EpDwGate>(p, s);
-    if (p.hw == 256) return launch_skinny_auto<8, 1, true, LdF32LN, EpDwGate>(p, s);
+    if (p.hw == 64 && big64 && p.M % 256 == 0 && (p.M / 64) * (p.N / 64) >= 1024) return launch_skinny_auto<8, 1, true, LN, EpDwGate>(p, s);
+    if (p.hw == 64) return launch_skinny_auto<2, 1, true, LN, EpDwGate>(p, s);
+    if (p.hw == 256) return launch_skinny_auto<8, 1, true, LN, EpDwGate>(p, s);
     return hipErrorInvalidValue;
 }
 bool dwgate_ok(int hw) { return hw == 1 || hw == 4 || hw == 16 || hw == 64 || hw == 256; }
 
 hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStream_t s) {
+    // LayerNorm GEMMs: which FiLM source the loader reads is a property of the kernel (LdF32LN: one row for all faces, in LDS;
+    // LdF32LNFace: per-face timesteps, rows of the global table) -- chosen here, never inside the K loop
+    const bool per_face = p.film_face_stride != 0;
     if (lk == LK_LN && ek == EK_DWGATE) {
         static const bool no_dw1 = hd_env("HD_NO_DW1") != nullptr;
-        if (p.hw == 1 && !no_dw1) return launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate1>(p, s);   // one pixel per face: element-wise
-        return dispatch_dwgate(p, s);
+        if (p.hw == 1 && !no_dw1)                                                                // one pixel per face: element-wise
+            return per_face ? launch_skinny_auto<1, 1, true, LdF32LNFace, EpDwGate1>(p, s) : launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate1>(p, s);
+        return per_face ? dispatch_dwgate<LdF32LNFace>(p, s) : dispatch_dwgate<LdF32LN>(p, s);
     }
-    if (lk == LK_LN && ek == EK_BIASF32) return launch_tile<LdF32LN, EpBiasF32, false>(p, mode, s);
-    if (lk == LK_LN && ek == EK_GATE) return launch_tile<LdF32LN, EpGateBF16, true>(p, mode, s);
+    if (lk == LK_LN && ek == EK_BIASF32) return per_face ? launch_tile<LdF32LNFace, EpBiasF32, false>(p, mode, s) : launch_tile<LdF32LN, EpBiasF32, false>(p, mode, s);
+    if (lk == LK_LN && ek == EK_GATE) return per_face ? launch_tile<LdF32LNFace, EpGateBF16, true>(p, mode, s) : launch_tile<LdF32LN, EpGateBF16, true>(p, mode, s);
     if (lk == LK_F32 && ek == EK_BIASF32) return launch_tile<LdF32Plain, EpBiasF32, false>(p, mode, s);
     if (lk == LK_F32 && ek == EK_PIXSHUF) return launch_tile<LdF32Plain, EpPixShufF32, false>(p, mode, s);
     if (lk == LK_BF16S && ek == EK_RESID) return launch_tile<LdBF16Scale, EpResidF32, false>(p, mode, s);
