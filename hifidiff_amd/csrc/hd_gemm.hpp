@@ -114,11 +114,11 @@ struct GemmP {
 #define HD_STAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    unsigned short a = __builtin_bit_cast(unsigned short, (__bf16)lo);
-    unsigned short b = __builtin_bit_cast(unsigned short, (__bf16)hi);
-    return (unsigned)a | ((unsigned)b << 16);
-}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 (round to nearest even) in one v_cvt_pk_bf16_f32; two scalar conversions cost two of them plus a merge
+__device__ __forceinline__ unsigned pack2(f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return pack2((f32x2_t){lo, hi}); }
 __device__ __forceinline__ uint4 pack8(const float* v) {
     return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
 }
@@ -368,7 +368,14 @@ struct LdF32LN_T {
         st.bias = f + p.film_bias_off;
     }
     static __device__ __forceinline__ void unit_stats(St& st, int row_local, const char* stats) {
-        const float2 s = reinterpret_cast<const float2*>(stats)[row_local];
+        float2 s = reinterpret_cast<const float2*>(stats)[row_local];
+        // The row statistics are read once and live in registers for the whole K loop, so their first use must see the
+        // complete LDS return.  In the straight-line K loop the compiler batches this read with the first gain / bias
+        // reads and resumes on a partial count (s_waitcnt lgkmcnt(5)) with the multiply below as the very next
+        // instruction; on MI355X that arrangement now and then computed mu from the previous contents of the register in
+        // lanes 48-63 (rows 8j+6, 8j+7 of a tile differed from launch to launch; tools/det_bench).  Consuming
+        // the read here, behind a full wait and a few idle cycles, removed it (0 of 6000 launches against >= 1 in 60).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(s.x), "+v"(s.y));
         st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
     }
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
@@ -405,6 +412,36 @@ struct LdF32LN_T {
         for (int i = 0; i < 8; ++i) v[i] = fmaf(fmaf(v[i], st.rstd, st.mu), g[i], b[i]);
         return pack8(v);
     }
+    // the same arithmetic (two fused multiply-adds per element, round to nearest even) for the straight-line K loop: no
+    // bounds (K % 64 == 0; a row beyond M re-reads row 0 with rstd = 0 and is never stored), two elements per
+    // instruction (v_pk_fma_f32, v_cvt_pk_bf16_f32).  This transform runs on every workgroup of every LayerNorm GEMM
+    // for all of its rows x K: it is VALU time on the critical path, not hidden behind the weight stream.
+    static __device__ __forceinline__ uint4 finish_nc(const GemmP& p, const St& st, int kc, int kq, const Raw& r) {
+        const int k = kc + 8 * kq;
+        f32x2_t g[4], b[4];
+        if constexpr (!PER_FACE) {
+            typedef __attribute__((address_space(3))) const f32x2_t lds_f2;
+            typedef __attribute__((address_space(3))) const float lds_f1;
+            lds_f1* gl = (lds_f1*)st.gbl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { g[i] = *(lds_f2*)(gl + k + 2 * i); b[i] = *(lds_f2*)(gl + p.Kp + k + 2 * i); }
+        } else {
+            typedef __attribute__((address_space(1))) const f32x2_t gl_f2;
+            typedef __attribute__((address_space(1))) const float gl_f1;
+            gl_f1 *gg = (gl_f1*)st.gain, *bg = (gl_f1*)st.bias;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { g[i] = *(gl_f2*)(gg + k + 2 * i); b[i] = *(gl_f2*)(bg + k + 2 * i); }
+        }
+        const unsigned w[4] = {r.x.x, r.x.y, r.x.z, r.x.w};
+        const f32x2_t rs = {st.rstd, st.rstd}, mu = {st.mu, st.mu};
+        unsigned o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2_t x = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+            o[i] = pack2(__builtin_elementwise_fma(__builtin_elementwise_fma(x, rs, mu), g[i], b[i]));
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    }
 };
 
 typedef LdF32LN_T<false> LdF32LN;          // one FiLM row for all faces
@@ -434,6 +471,7 @@ struct LdBF16Plain {
     static __device__ __forceinline__ uint4 finish(const GemmP&, const St& st, int, int, const Raw& r) {
         return st.valid ? r.x : make_uint4(0, 0, 0, 0);
     }
+    static __device__ __forceinline__ uint4 finish_nc(const GemmP& p, const St& st, int kc, int kq, const Raw& r) { return finish(p, st, kc, kq, r); }
 };
 
 // bf16 rows times a per-(face, k) fp32 scale: x * sca(x) feeding conv3 (conditional_naf.py:119-120)
@@ -1082,6 +1120,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         for (int tn = 0; tn < TNT; ++tn)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][tn][i] = 0.f;
+    if constexpr (CPW > 0) {
+        // Keep the zero accumulators in registers.  In straight-line code the compiler folds them into the first MFMA of
+        // each tile as the inline constant 0 (v_mfma D, A, B, 0) and is then free to allocate D on top of that
+        // instruction's own A / B registers (seen: D = v[2:17], A = v[10:13], B = v[6:9]); the 16-pass MFMA does not read
+        // its operands before it starts writing D, and the result changed from launch to launch (tools/det_bench).
+        // With a register source C the accumulate form D == C is used, which never overlaps A or B.
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int tn = 0; tn < TNT; ++tn) asm volatile("" : "+v"(acc[mt][tn]));
+    }
 
     uint4 bq[D][4][TNT];
     typename LD::Raw aq[D][UN];
@@ -1177,8 +1226,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     }
     auto chunk_mma = [&](int d, int cc) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u)
-            lds_write_unit<LD::kSplit>(sA + u_off[u], kq, LD::finish(p, st[u], cc * BK, kq, aq[d][u]));
+        for (int u = 0; u < UN; ++u) {
+            uint4 unit;
+            if constexpr (CPW > 0) unit = LD::finish_nc(p, st[u], cc * BK, kq, aq[d][u]);
+            else unit = LD::finish(p, st[u], cc * BK, kq, aq[d][u]);
+            lds_write_unit<LD::kSplit>(sA + u_off[u], kq, unit);
+        }
         __builtin_amdgcn_wave_barrier();                           // LDS ops of one wave execute in order
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
@@ -1406,9 +1459,9 @@ inline hipError_t launch_skinny(const GemmP& p, hipStream_t s) {
     const int smem = C::GB_OFF + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0);
     if (smem > 160 * 1024 || (p.Kp / 64) % C::WK != 0) return hipErrorInvalidValue;
     const bool nt = p.w_nt != 0;
-    // the hot shapes (K split over 8 waves, 2 or 4 chunks each, K a multiple of 64, whole weight tiles) get the
-    // straight-line K loop (gemm_skinny_kernel, CPW)
-    if constexpr (LD::kStaticK && C::WK == 8) {
+    // 2 or 4 chunks per wave, K a multiple of 64, whole weight tiles (every GEMM of the denoiser blocks from level 0 to
+    // the middle): the straight-line K loop (gemm_skinny_kernel, CPW)
+    if constexpr (LD::kStaticK) {
         static const bool no_static = hd_env("HD_NO_STATIC_K") != nullptr;
         const int cpw = (p.Kp / 64) / C::WK;
         const int ncols = (C::TNT == 2) ? p.N / 2 : p.N;

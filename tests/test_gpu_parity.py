@@ -204,6 +204,15 @@ def test_latent32_against_reference_golden(gpu):
     assert psnr(lat, golden("ddim250_first20_L32.npz")["final"]) >= 40.0
 
 
+def test_every_launch_is_reproducible(gpu, weights16):
+    """Each launch of the denoiser program, run three times on the same inputs, gives the same bits (fixed reduction orders,
+    no float atomics, and no dependence on how loads and LDS returns happen to be timed: the straight-line K loop once
+    failed exactly this, in rows 8j+6 / 8j+7 of one tile in one launch out of tens)."""
+    import determinism_scan
+    n, bad = determinism_scan.scan(64, 16, 3, model=make_model(weights16), verbose=False)
+    assert n > 100 and not bad, bad
+
+
 def test_full_batch_properties(gpu, weights16):
     """Benchmark batch (64 faces): determinism, agreement with the small-batch run, chain split invariance."""
     from hifidiff_amd import sampling, schedulers, synth

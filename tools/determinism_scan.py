@@ -1,0 +1,60 @@
+"""Find the first launch of the denoiser program whose output differs between two identical runs (GPU).
+
+usage: python tools/determinism_scan.py [batch] [latent] [repeats]
+Every launch is meant to be bitwise reproducible (fixed reduction orders, no float atomics); a launch that is not has a
+race or reads something uninitialised.  Runs the program up to launch i twice (hd_debug_limit_ops) and compares its output.
+"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hifidiff_amd import _lib, refiner, synth
+from tools.op_parity import read_op
+
+
+def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5):
+    """Returns (launches scanned, [(index, name, differing values, max abs difference), ...])."""
+    m = model
+    if m is None:
+        m = refiner.FacialRefiner(latent)
+        m.load_state_dict(synth.refiner_state_dict(latent))
+        m.to("cuda")
+    x, crl, crf = [t.cuda() for t in synth.sample_inputs(B, latent)]
+    e = m.engine
+    e.prepare(crl, cr_face=crf)
+    L = _lib.lib()
+    t = torch.full((B,), 500.0, device="cuda")
+    n = L.hd_num_ops(e.ctx, 0)
+    bad = []
+    for i in range(n):
+        name = L.hd_debug_op_name(e.ctx, 0, i).decode()
+        L.hd_debug_limit_ops(e.ctx, 0, i + 1)
+        outs = []
+        for _ in range(reps):
+            e.eps(x, t)
+            torch.cuda.synchronize()
+            outs.append(read_op(L, e.ctx, 0, i).numpy().copy())
+        same = all(np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)) for o in outs[1:])
+        if not same:
+            d = max(float(np.abs(outs[0] - o).max()) for o in outs[1:])
+            nd = max(int((outs[0].view(np.uint32) != o.view(np.uint32)).sum()) for o in outs[1:])
+            if verbose:
+                print(f"{i:3d} {name:45s} DIFFERS: {nd} of {outs[0].size} values, max abs {d:.3e}", flush=True)
+            bad.append((i, name, nd, d))
+            if len(bad) >= max_bad:
+                break
+    L.hd_debug_limit_ops(e.ctx, 0, -1)
+    return n, bad
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    latent = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    n, bad = scan(B, latent, reps)
+    print(f"{n} launches scanned, {len(bad)} not reproducible")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

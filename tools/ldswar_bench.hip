@@ -1,0 +1,83 @@
+// ldswar_bench.hip — is the data of a 128-bit LDS store safe from an LDS load that follows it and returns into the same
+// registers? (tools only)      build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/ldswar_bench_bin tools/ldswar_bench.hip
+// Each wave: v[40:43] = a pattern unique per lane; ds_write_b128 (row stride 144 B, as the GEMM staging tiles);
+// immediately ds_read2_b64 v[40:43] from a table of 0xAAAAAAAA; wait; read the stored row back and compare.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int MODE>     // 0: store then load into the same registers; 1: VALU writes the last data register right before the store
+__global__ __launch_bounds__(512) void war_kernel(unsigned* bad, unsigned* bad_lane_hist, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * 4608 + 4096];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned* table = reinterpret_cast<unsigned*>(smem + 8 * 4608);
+    for (int i = tid; i < 1024; i += 512) table[i] = 0xAAAAAAAAu;
+    __syncthreads();
+    const unsigned wbase = wave * 4608 + (lane >> 3) * 144 + (lane & 7) * 16;      // unit layout of the skinny GEMM
+    const unsigned raddr = 8 * 4608 + (lane & 7) * 32;
+    unsigned nbad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned pat = (unsigned)(blockIdx.x * 131 + it * 7 + tid) * 2654435761u | 1u;
+        unsigned r0, r1, r2, r3;
+        if (MODE == 0)
+            asm volatile("v_mov_b32 v40, %4\n\tv_add_u32 v41, 1, %4\n\tv_add_u32 v42, 2, %4\n\tv_add_u32 v43, 3, %4\n\t"
+                         "s_nop 4\n\t"
+                         "ds_write_b128 %5, v[40:43]\n\t"
+                         "ds_read2_b64 v[40:43], %6 offset1:1\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "ds_read_b128 v[44:47], %5\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_mov_b32 %0, v44\n\tv_mov_b32 %1, v45\n\tv_mov_b32 %2, v46\n\tv_mov_b32 %3, v47"
+                         : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"(pat), "v"(wbase), "v"(raddr)
+                         : "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+        else if (MODE == 2) {                                     // store, four loads, lgkmcnt(1), use the third load at once
+            asm volatile("v_mov_b32 v40, %4\n\tv_add_u32 v41, 1, %4\n\tv_add_u32 v42, 2, %4\n\tv_add_u32 v43, 3, %4\n\t"
+                         "v_mov_b32 v52, 0\n\tv_mov_b32 v53, 0\n\tv_mov_b32 v54, 0\n\tv_mov_b32 v55, 0\n\t"
+                         "s_nop 4\n\t"
+                         "ds_write_b128 %5, v[40:43]\n\t"
+                         "ds_read2_b64 v[44:47], %6 offset1:1\n\t"
+                         "ds_read2_b64 v[48:51], %6 offset0:2 offset1:3\n\t"
+                         "ds_read2_b64 v[52:55], %6 offset0:4 offset1:5\n\t"
+                         "ds_read2_b64 v[56:59], %6 offset0:6 offset1:7\n\t"
+                         "s_waitcnt lgkmcnt(1)\n\t"
+                         "v_mov_b32 %0, v52\n\tv_mov_b32 %1, v53\n\tv_mov_b32 %2, v54\n\tv_mov_b32 %3, v55\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"(pat), "v"(wbase), "v"(raddr)
+                         : "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+            const bool ok2 = r0 == 0xAAAAAAAAu && r1 == 0xAAAAAAAAu && r2 == 0xAAAAAAAAu && r3 == 0xAAAAAAAAu;
+            if (!ok2) { ++nbad; atomicAdd(&bad_lane_hist[lane], 1u); }
+            continue;
+        } else
+            asm volatile("v_mov_b32 v40, %4\n\tv_add_u32 v41, 1, %4\n\tv_add_u32 v42, 2, %4\n\tv_mov_b32 v43, 0\n\t"
+                         "s_nop 4\n\t"
+                         "v_add_u32 v43, 3, %4\n\t"
+                         "ds_write_b128 %5, v[40:43]\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "ds_read_b128 v[44:47], %5\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_mov_b32 %0, v44\n\tv_mov_b32 %1, v45\n\tv_mov_b32 %2, v46\n\tv_mov_b32 %3, v47"
+                         : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"(pat), "v"(wbase), "v"(raddr)
+                         : "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+        const bool ok = r0 == pat && r1 == pat + 1 && r2 == pat + 2 && r3 == pat + 3;
+        if (!ok) { ++nbad; atomicAdd(&bad_lane_hist[lane], 1u); }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+int main() {
+    unsigned *bad, *hist;
+    CK(hipMalloc(&bad, 4)); CK(hipMalloc(&hist, 256));
+    for (int mode = 0; mode < 3; ++mode) {
+        CK(hipMemset(bad, 0, 4)); CK(hipMemset(hist, 0, 256));
+        if (mode == 0) hipLaunchKernelGGL(war_kernel<0>, dim3(1024), dim3(512), 0, 0, bad, hist, 2000);
+        else if (mode == 2) hipLaunchKernelGGL(war_kernel<2>, dim3(1024), dim3(512), 0, 0, bad, hist, 2000);
+        else hipLaunchKernelGGL(war_kernel<1>, dim3(1024), dim3(512), 0, 0, bad, hist, 2000);
+        CK(hipDeviceSynchronize());
+        unsigned h, hl[64]; CK(hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl, hist, 256, hipMemcpyDeviceToHost));
+        printf("mode %d: %u corrupted stores of %u", mode, h, 1024u * 512u * 2000u);
+        if (h) { printf("; by lane:"); for (int l = 0; l < 64; ++l) if (hl[l]) printf(" %d:%u", l, hl[l]); }
+        printf("\n");
+    }
+    return 0;
+}
