@@ -16,7 +16,9 @@ import torch  # noqa: F401  (load order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhifidiff_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_gemm.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_tail.hpp", "hd_vae.hpp")]
+# translation units (compiled in parallel, one hipcc each) and the headers they include
+UNITS = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_dispatch_ln.hip", "hd_dispatch_lnface.hip", "hd_dispatch_bf16.hip", "hd_dispatch_misc.hip")]
+SOURCES = UNITS + [os.path.join(_HERE, "csrc", f) for f in ("hd_gemm.hpp", "hd_dispatch.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_tail.hpp", "hd_vae.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
 
 EXPORTS = [
@@ -43,11 +45,22 @@ def build(force=False, verbose=False):
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
-           "-o", LIB_PATH, SOURCES[0]]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    objdir = os.path.join(_HERE, "csrc", "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = [os.path.join(objdir, os.path.splitext(os.path.basename(u))[0] + ".o") for u in UNITS]
+    cmds = [[hipcc] + flags + ["-c", u, "-o", o] for u, o in zip(UNITS, objs)]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        for c in cmds:
+            print(" ".join(c))
+    procs = [subprocess.Popen(c) for c in cmds]                 # the kernel instantiations dominate: one process per unit
+    failed = [u for u, pr in zip(UNITS, procs) if pr.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(os.path.basename(f) for f in failed))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(link))
+    subprocess.run(link, check=True)
     return LIB_PATH
 
 

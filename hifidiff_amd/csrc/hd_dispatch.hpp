@@ -1,0 +1,70 @@
+// hd_dispatch.hpp -- the GEMM launch table, split by loader family so that the kernel instantiations compile in parallel
+// translation units (hd_dispatch_*.hip; one hipcc process each, linked into libhifidiff_hip.so).
+#pragma once
+#include "hd_gemm.hpp"
+
+namespace hd {
+
+enum LdKind { LK_F32, LK_LN, LK_BF16, LK_BF16S, LK_CONV_F32, LK_CONV_F32G, LK_CONV_BF16 };
+enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE, EK_SCA };
+
+// mode: 0 = tall T128, 1 = tall T64, 2 = skinny 64 rows, 3 = skinny 32 rows, 4 = tall T32W (32 rows x 256 cols),
+//       5 / 6 = skinny with 4 / 8 M-split waves (128 / 256 rows per workgroup; long-K gathers at large M)
+template <class LD, class EP, bool PAIR>
+hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
+    if constexpr (PAIR) {
+        switch (mode) {
+            case 0: return launch_gemm<T128P, LD, EP>(p, s);
+            case 1: return launch_gemm<T64P, LD, EP>(p, s);
+            case 2: return launch_skinny_auto<1, 2, true, LD, EP>(p, s);
+            case 4: return launch_gemm<T32WP, LD, EP>(p, s);
+            case 5: return launch_skinny_auto<4, 1, true, LD, EP>(p, s);
+            case 6: return launch_skinny_auto<8, 1, true, LD, EP>(p, s);
+            default: return launch_skinny_auto<1, 1, true, LD, EP>(p, s);
+        }
+    } else {
+        switch (mode) {
+            case 0: return launch_gemm<T128, LD, EP>(p, s);
+            case 1: return launch_gemm<T64, LD, EP>(p, s);
+            case 2: return launch_skinny_auto<1, 2, false, LD, EP>(p, s);
+            case 4: return launch_gemm<T32W, LD, EP>(p, s);
+            case 5: return launch_skinny_auto<4, 1, false, LD, EP>(p, s);
+            case 6: return launch_skinny_auto<8, 1, false, LD, EP>(p, s);
+            default: return launch_skinny_auto<1, 1, false, LD, EP>(p, s);
+        }
+    }
+}
+
+// conv1 with the depthwise 3x3 + SimpleGate + pool fused: workgroup = whole faces (BM = max(32, hw) rows)
+template <class LN>
+hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
+    // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle)
+    if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LN, EpDwGate>(p, s);
+    if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LN, EpDwGate>(p, s);
+    static const bool big64 = hd_env("HD_NO_DW64_WM8") == nullptr;      // 256-row tiles (4 faces of 8x8) when 64-row tiles would put >= 4 workgroups on a CU
+    if (p.hw == 64 && big64 && p.M % 256 == 0 && (p.M / 64) * (p.N / 64) >= 1024) return launch_skinny_auto<8, 1, true, LN, EpDwGate>(p, s);
+    if (p.hw == 64) return launch_skinny_auto<2, 1, true, LN, EpDwGate>(p, s);
+    if (p.hw == 256) return launch_skinny_auto<8, 1, true, LN, EpDwGate>(p, s);
+    return hipErrorInvalidValue;
+}
+
+// LayerNorm GEMMs (LK_LN): which FiLM source the loader reads is a property of the kernel (LdF32LN: one row for all faces, in
+// LDS; LdF32LNFace: per-face timesteps, rows of the global table) -- chosen by the caller, never inside the K loop
+template <class LN>
+hipError_t dispatch_ln(const GemmP& p, EpKind ek, int mode, hipStream_t s) {
+    if (ek == EK_DWGATE) {
+        static const bool no_dw1 = hd_env("HD_NO_DW1") != nullptr;
+        if (p.hw == 1 && !no_dw1) return launch_skinny_auto<1, 1, true, LN, EpDwGate1>(p, s);     // one pixel per face: element-wise
+        return dispatch_dwgate<LN>(p, s);
+    }
+    if (ek == EK_BIASF32) return launch_tile<LN, EpBiasF32, false>(p, mode, s);
+    if (ek == EK_GATE) return launch_tile<LN, EpGateBF16, true>(p, mode, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t dispatch_gemm_ln_shared(const GemmP& p, EpKind ek, int mode, hipStream_t s);     // hd_dispatch_ln.hip
+hipError_t dispatch_gemm_ln_face(const GemmP& p, EpKind ek, int mode, hipStream_t s);       // hd_dispatch_lnface.hip
+hipError_t dispatch_gemm_bf16(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStream_t s);   // hd_dispatch_bf16.hip: LK_BF16, LK_BF16S
+hipError_t dispatch_gemm_misc(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStream_t s);   // hd_dispatch_misc.hip: LK_F32, LK_CONV_BF16
+
+}  // namespace hd

@@ -17,6 +17,7 @@
 #include "hd_chain.hpp"
 #include "hd_conv.hpp"
 #include "hd_cr.hpp"
+#include "hd_dispatch.hpp"
 #include "hd_gemm.hpp"
 #include "hd_kernels.hpp"
 #include "hd_tail.hpp"
@@ -62,8 +63,6 @@ struct HcaW {
 struct ResConv { PackedW w; int cin, cout, k, stride, pad; };
 struct ResBlock { ResConv c1, c2, c3, ds; bool has_ds = false; };
 
-enum LdKind { LK_F32, LK_LN, LK_BF16, LK_BF16S, LK_CONV_F32, LK_CONV_F32G, LK_CONV_BF16 };
-enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE, EK_SCA };
 
 struct Op {
     std::string name;
@@ -520,75 +519,13 @@ int pack_weight(hd_ctx* c, const std::string& name, PackedW* out, const PackOpts
 }
 
 // ------------------------------------------------------------------------------------ GEMM dispatch
-// mode: 0 = tall T128, 1 = tall T64, 2 = skinny 64 rows, 3 = skinny 32 rows, 4 = tall T32W (32 rows x 256 cols),
-//       5 / 6 = skinny with 4 / 8 M-split waves (128 / 256 rows per workgroup; long-K gathers at large M)
-template <class LD, class EP, bool PAIR>
-hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
-    if constexpr (PAIR) {
-        switch (mode) {
-            case 0: return launch_gemm<T128P, LD, EP>(p, s);
-            case 1: return launch_gemm<T64P, LD, EP>(p, s);
-            case 2: return launch_skinny_auto<1, 2, true, LD, EP>(p, s);
-            case 4: return launch_gemm<T32WP, LD, EP>(p, s);
-            case 5: return launch_skinny_auto<4, 1, true, LD, EP>(p, s);
-            case 6: return launch_skinny_auto<8, 1, true, LD, EP>(p, s);
-            default: return launch_skinny_auto<1, 1, true, LD, EP>(p, s);
-        }
-    } else {
-        switch (mode) {
-            case 0: return launch_gemm<T128, LD, EP>(p, s);
-            case 1: return launch_gemm<T64, LD, EP>(p, s);
-            case 2: return launch_skinny_auto<1, 2, false, LD, EP>(p, s);
-            case 4: return launch_gemm<T32W, LD, EP>(p, s);
-            case 5: return launch_skinny_auto<4, 1, false, LD, EP>(p, s);
-            case 6: return launch_skinny_auto<8, 1, false, LD, EP>(p, s);
-            default: return launch_skinny_auto<1, 1, false, LD, EP>(p, s);
-        }
-    }
-}
-
-// conv1 with the depthwise 3x3 + SimpleGate + pool fused: workgroup = whole faces (BM = max(32, hw) rows)
-template <class LN>
-hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
-    // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle)
-    if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LN, EpDwGate>(p, s);
-    if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LN, EpDwGate>(p, s);
-    static const bool big64 = hd_env("HD_NO_DW64_WM8") == nullptr;      // 256-row tiles (4 faces of 8x8) when 64-row tiles would put >= 4 workgroups on a CU
-    if (p.hw == 64 && big64 && p.M % 256 == 0 && (p.M / 64) * (p.N / 64) >= 1024) return launch_skinny_auto<8, 1, true, LN, EpDwGate>(p, s);
-    if (p.hw == 64) return launch_skinny_auto<2, 1, true, LN, EpDwGate>(p, s);
-    if (p.hw == 256) return launch_skinny_auto<8, 1, true, LN, EpDwGate>(p, s);
-    return hipErrorInvalidValue;
-}
+// (the launch table lives in hd_dispatch.hpp / hd_dispatch_*.hip, one translation unit per loader family)
 bool dwgate_ok(int hw) { return hw == 1 || hw == 4 || hw == 16 || hw == 64 || hw == 256; }
 
 hipError_t dispatch_gemm(const GemmP& p, LdKind lk, EpKind ek, int mode, hipStream_t s) {
-    // LayerNorm GEMMs: which FiLM source the loader reads is a property of the kernel (LdF32LN: one row for all faces, in LDS;
-    // LdF32LNFace: per-face timesteps, rows of the global table) -- chosen here, never inside the K loop
-    const bool per_face = p.film_face_stride != 0;
-    if (lk == LK_LN && ek == EK_DWGATE) {
-        static const bool no_dw1 = hd_env("HD_NO_DW1") != nullptr;
-        if (p.hw == 1 && !no_dw1)                                                                // one pixel per face: element-wise
-            return per_face ? launch_skinny_auto<1, 1, true, LdF32LNFace, EpDwGate1>(p, s) : launch_skinny_auto<1, 1, true, LdF32LN, EpDwGate1>(p, s);
-        return per_face ? dispatch_dwgate<LdF32LNFace>(p, s) : dispatch_dwgate<LdF32LN>(p, s);
-    }
-    if (lk == LK_LN && ek == EK_BIASF32) return per_face ? launch_tile<LdF32LNFace, EpBiasF32, false>(p, mode, s) : launch_tile<LdF32LN, EpBiasF32, false>(p, mode, s);
-    if (lk == LK_LN && ek == EK_GATE) return per_face ? launch_tile<LdF32LNFace, EpGateBF16, true>(p, mode, s) : launch_tile<LdF32LN, EpGateBF16, true>(p, mode, s);
-    if (lk == LK_F32 && ek == EK_BIASF32) return launch_tile<LdF32Plain, EpBiasF32, false>(p, mode, s);
-    if (lk == LK_F32 && ek == EK_PIXSHUF) return launch_tile<LdF32Plain, EpPixShufF32, false>(p, mode, s);
-    if (lk == LK_BF16S && ek == EK_RESID) return launch_tile<LdBF16Scale, EpResidF32, false>(p, mode, s);
-    if (lk == LK_BF16 && ek == EK_RESID) return launch_tile<LdBF16Plain, EpResidF32, false>(p, mode, s);
-    if (lk == LK_BF16 && ek == EK_BIASBF16) return launch_tile<LdBF16Plain, EpBiasBF16, false>(p, mode, s);
-    if (lk == LK_CONV_BF16 && ek == EK_BIASF32) return launch_tile<LdConv<true, false>, EpBiasF32, false>(p, mode, s);
-    if (lk == LK_BF16 && ek == EK_PIXSHUF) return launch_tile<LdBF16Plain, EpPixShufF32, false>(p, mode, s);
-    if (lk == LK_BF16 && ek == EK_SCA) {
-        static const bool no_dw1 = hd_env("HD_NO_DW1") != nullptr;
-        if (p.scale_hw == 1 && !no_dw1) return launch_skinny_auto<1, 1, false, LdBF16Plain, EpSca1BF16>(p, s);
-        return launch_skinny_auto<1, 1, false, LdBF16Plain, EpScaBF16>(p, s);   // its in-place G scaling is a skinny tile epilogue
-    }
-    if (lk == LK_CONV_BF16 && ek == EK_BIASBF16) return launch_tile<LdConv<true, false>, EpBiasBF16, false>(p, mode, s);
-    if (lk == LK_CONV_BF16 && ek == EK_RESID) return launch_tile<LdConv<true, false>, EpResidF32, false>(p, mode, s);      // VAE ResnetBlock2D conv2 + shortcut
-    if (lk == LK_BF16 && ek == EK_BIASF32) return launch_tile<LdBF16Plain, EpBiasF32, false>(p, mode, s);                  // VAE attention projections
-    return hipErrorInvalidValue;
+    if (lk == LK_LN) return p.film_face_stride != 0 ? dispatch_gemm_ln_face(p, ek, mode, s) : dispatch_gemm_ln_shared(p, ek, mode, s);
+    if (lk == LK_BF16 || lk == LK_BF16S) return dispatch_gemm_bf16(p, lk, ek, mode, s);
+    return dispatch_gemm_misc(p, lk, ek, mode, s);
 }
 
 // Kernel choice: tall tiles while they still give >= 256 workgroups (256 CUs); otherwise the skinny
