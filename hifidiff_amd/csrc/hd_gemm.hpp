@@ -349,6 +349,7 @@ struct LdF32LN_T {
                 if (part == 0 && rl < BM) st[rl] = make_float2(mean, n > 0.f ? 1.0f / sqrtf(m2 / n + p.ln_eps) : 0.f);
             }
         }
+        HD_STAMP(7);
         __syncthreads();
     }
     template <int BM, int THREADS> static __device__ void block_init(const GemmP& p, int row0, char* stats, float* gb, int tid) {
@@ -369,12 +370,15 @@ struct LdF32LN_T {
     }
     static __device__ __forceinline__ void unit_stats(St& st, int row_local, const char* stats) {
         float2 s = reinterpret_cast<const float2*>(stats)[row_local];
-        // The row statistics are read once and live in registers for the whole K loop, so their first use must see the
-        // complete LDS return.  In the straight-line K loop the compiler batches this read with the first gain / bias
-        // reads and resumes on a partial count (s_waitcnt lgkmcnt(5)) with the multiply below as the very next
-        // instruction; on MI355X that arrangement now and then computed mu from the previous contents of the register in
-        // lanes 48-63 (rows 8j+6, 8j+7 of a tile differed from launch to launch; tools/det_bench).  Consuming
-        // the read here, behind a full wait and a few idle cycles, removed it (0 of 6000 launches against >= 1 in 60).
+        // The row statistics are read once and live in registers for the whole K loop.  In the straight-line K loop the
+        // compiler batches this read with the first gain / bias reads and resumes on a partial count (s_waitcnt
+        // lgkmcnt(5)) with the multiply below as the next instruction; in that form rows 8j+6 / 8j+7 of a tile (lanes
+        // 48-63 of a unit) came out different in >= 1 launch of 60 on MI355X, and only when the transform used these
+        // values (constants instead: reproducible).  Consuming the read here behind a full wait gives 0 of 5400 launches
+        // (tools/det_bench).  The cause is not established: checks of the ordering rules this could have broken -- vector
+        // loads and LDS returns against their counters, a 128-bit LDS store against the VALU write before it and the LDS
+        // load after it, an MFMA whose D overlaps its A / B -- all came back clean (tools/vmorder_bench, ldswar_bench,
+        // mfma_overlap_bench).  tests/test_gpu_parity.py::test_every_launch_is_reproducible guards it.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(s.x), "+v"(s.y));
         st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
     }
@@ -1120,18 +1124,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         for (int tn = 0; tn < TNT; ++tn)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][tn][i] = 0.f;
-    if constexpr (CPW > 0) {
-        // Keep the zero accumulators in registers.  In straight-line code the compiler folds them into the first MFMA of
-        // each tile as the inline constant 0 (v_mfma D, A, B, 0) and is then free to allocate D on top of that
-        // instruction's own A / B registers (seen: D = v[2:17], A = v[10:13], B = v[6:9]); the 16-pass MFMA does not read
-        // its operands before it starts writing D, and the result changed from launch to launch (tools/det_bench).
-        // With a register source C the accumulate form D == C is used, which never overlaps A or B.
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int tn = 0; tn < TNT; ++tn) asm volatile("" : "+v"(acc[mt][tn]));
-    }
-
     uint4 bq[D][4][TNT];
     typename LD::Raw aq[D][UN];
 #define HD_SK_LOAD_B(slot, chunk)                                                                      \

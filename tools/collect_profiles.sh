@@ -21,6 +21,7 @@ python tools/kernel_table.py "$TRACE" "$OUT/ops.txt" > "$OUT/kernel_table.txt"
 cp "$STATS" "$OUT/kernel_stats.csv"
 rm -f "$TRACE"                                     # tens of MB; the summary and stats are what is kept
 grep "steps x" "$OUT/kernel_trace_summary.txt"
+if [ -n "$ONLY_TRACE" ]; then echo "trace only"; exit 0; fi      # ONLY_TRACE=1: the per-kernel table, nothing else
 
 # 2. HBM traffic: one counter per pass, two lengths, difference isolates the replay loop
 for C in FETCH_SIZE WRITE_SIZE; do

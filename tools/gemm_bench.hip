@@ -70,6 +70,8 @@ static void report_stamps(unsigned long long* dev, int nwg) {
     for (int i = 0; i < 5; ++i) { std::sort(d[i].begin(), d[i].end()); printf(" %s %.2f/%.2f", nm[i], d[i][d[i].size() / 2], d[i].back()); }
     { std::vector<double> q; for (int w = 0; w < nwg; ++w) if (h[(size_t)w * 8 + 6]) q.push_back((double)(h[(size_t)w * 8 + 6] - h[(size_t)w * 8]) * 0.01);
       if (!q.empty()) { std::sort(q.begin(), q.end()); printf(" | loads-issued@ %.2f/%.2f", q[q.size() / 2], q.back()); } }
+    { std::vector<double> q; for (int w = 0; w < nwg; ++w) if (h[(size_t)w * 8 + 7]) q.push_back((double)(h[(size_t)w * 8 + 7] - h[(size_t)w * 8]) * 0.01);
+      if (!q.empty()) { std::sort(q.begin(), q.end()); printf(" stats-merged@ %.2f/%.2f", q[q.size() / 2], q.back()); } }
     printf("\n");
 }
 
