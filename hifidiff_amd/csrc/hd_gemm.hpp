@@ -420,29 +420,39 @@ struct LdF32LN_T {
     // bounds (K % 64 == 0; a row beyond M re-reads row 0 with rstd = 0 and is never stored), two elements per
     // instruction (v_pk_fma_f32, v_cvt_pk_bf16_f32).  This transform runs on every workgroup of every LayerNorm GEMM
     // for all of its rows x K: it is VALU time on the critical path, not hidden behind the weight stream.
-    static __device__ __forceinline__ uint4 finish_nc(const GemmP& p, const St& st, int kc, int kq, const Raw& r) {
-        const int k = kc + 8 * kq;
-        f32x2_t g[4], b[4];
+    // gain / bias of the lane's eight k: the same for every row when all faces share one FiLM row, so they are read from
+    // LDS once per chunk, not once per (row, 8 k) unit (the compiler cannot merge the reads itself: an LDS store of the
+    // staging tile sits between two units)
+    struct ChunkC { f32x2_t g[4], b[4]; };
+    static __device__ __forceinline__ void film8(const GemmP& p, const St& st, int k, ChunkC& c) {
         if constexpr (!PER_FACE) {
             typedef __attribute__((address_space(3))) const f32x2_t lds_f2;
             typedef __attribute__((address_space(3))) const float lds_f1;
             lds_f1* gl = (lds_f1*)st.gbl;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { g[i] = *(lds_f2*)(gl + k + 2 * i); b[i] = *(lds_f2*)(gl + p.Kp + k + 2 * i); }
+            for (int i = 0; i < 4; ++i) { c.g[i] = *(lds_f2*)(gl + k + 2 * i); c.b[i] = *(lds_f2*)(gl + p.Kp + k + 2 * i); }
         } else {
             typedef __attribute__((address_space(1))) const f32x2_t gl_f2;
             typedef __attribute__((address_space(1))) const float gl_f1;
             gl_f1 *gg = (gl_f1*)st.gain, *bg = (gl_f1*)st.bias;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { g[i] = *(gl_f2*)(gg + k + 2 * i); b[i] = *(gl_f2*)(bg + k + 2 * i); }
+            for (int i = 0; i < 4; ++i) { c.g[i] = *(gl_f2*)(gg + k + 2 * i); c.b[i] = *(gl_f2*)(bg + k + 2 * i); }
         }
+    }
+    static __device__ __forceinline__ void chunk_consts(const GemmP& p, const St& st0, int kc, int kq, ChunkC& c) {
+        if constexpr (!PER_FACE) film8(p, st0, kc + 8 * kq, c);
+    }
+    static __device__ __forceinline__ uint4 finish_nc(const GemmP& p, const St& st, int kc, int kq, const Raw& r, const ChunkC& cc) {
+        ChunkC own;
+        if constexpr (PER_FACE) film8(p, st, kc + 8 * kq, own);      // rows of different faces: per unit
+        const ChunkC& c = PER_FACE ? own : cc;
         const unsigned w[4] = {r.x.x, r.x.y, r.x.z, r.x.w};
         const f32x2_t rs = {st.rstd, st.rstd}, mu = {st.mu, st.mu};
         unsigned o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x2_t x = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
-            o[i] = pack2(__builtin_elementwise_fma(__builtin_elementwise_fma(x, rs, mu), g[i], b[i]));
+            o[i] = pack2(__builtin_elementwise_fma(__builtin_elementwise_fma(x, rs, mu), c.g[i], c.b[i]));
         }
         return make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -475,7 +485,9 @@ struct LdBF16Plain {
     static __device__ __forceinline__ uint4 finish(const GemmP&, const St& st, int, int, const Raw& r) {
         return st.valid ? r.x : make_uint4(0, 0, 0, 0);
     }
-    static __device__ __forceinline__ uint4 finish_nc(const GemmP& p, const St& st, int kc, int kq, const Raw& r) { return finish(p, st, kc, kq, r); }
+    struct ChunkC {};
+    static __device__ __forceinline__ void chunk_consts(const GemmP&, const St&, int, int, ChunkC&) {}
+    static __device__ __forceinline__ uint4 finish_nc(const GemmP& p, const St& st, int kc, int kq, const Raw& r, const ChunkC&) { return finish(p, st, kc, kq, r); }
 };
 
 // bf16 rows times a per-(face, k) fp32 scale: x * sca(x) feeding conv3 (conditional_naf.py:119-120)
@@ -1217,12 +1229,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
         __builtin_amdgcn_wave_barrier();
     }
     auto chunk_mma = [&](int d, int cc) {
+        if constexpr (CPW > 0) {
+            typename LD::ChunkC chunk_c;
+            LD::chunk_consts(p, st[0], cc * BK, kq, chunk_c);
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            uint4 unit;
-            if constexpr (CPW > 0) unit = LD::finish_nc(p, st[u], cc * BK, kq, aq[d][u]);
-            else unit = LD::finish(p, st[u], cc * BK, kq, aq[d][u]);
-            lds_write_unit<LD::kSplit>(sA + u_off[u], kq, unit);
+            for (int u = 0; u < UN; ++u) lds_write_unit<LD::kSplit>(sA + u_off[u], kq, LD::finish_nc(p, st[u], cc * BK, kq, aq[d][u], chunk_c));
+        } else {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) lds_write_unit<LD::kSplit>(sA + u_off[u], kq, LD::finish(p, st[u], cc * BK, kq, aq[d][u]));
         }
         __builtin_amdgcn_wave_barrier();                           // LDS ops of one wave execute in order
 #pragma unroll
