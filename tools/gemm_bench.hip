@@ -176,6 +176,7 @@ int main(int argc, char** argv) {
         RUN_SK("skinny LN bias MT1 W8 D4", 1, 8, false, 4, LdF32LN, EpBiasF32, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in))
         RUN_SK("skinny LN gate(pair) MT1 W8 D2", 1, 8, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SK("skinny LN gate(pair) MT2 W8 D1", 2, 8, true, 1, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SK("skinny LN gate(pair) MT2 W8 D2", 2, 8, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SK("skinny bf16plain gate(pair) MT1 W8 D2 (no LN)", 1, 8, true, 2, LdBF16Plain, EpGateBF16, (p.A = Ab, p.lda = LDA, p.out = b.outb, p.ldo = N / 2))
         RUN_SK("skinny bf16plain bias MT1 W8 D2 (no LN)", 1, 8, false, 2, LdBF16Plain, EpBiasF32, (p.A = Ab, p.lda = LDA))
         // four waves per workgroup (one per SIMD: up to 512 VGPRs each): the whole K slice of a wave in flight
