@@ -213,6 +213,9 @@ int main(int argc, char** argv) {
         RUN_SKW("skinny W8 LN dwgate hw4 (L3 conv1 fused)", 1, 8, 1, true, 2, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = 4, p.side = 2))
         RUN_SKW("skinny W8 LN dwgate hw16 (L2 conv1 fused)", 1, 8, 1, true, 2, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = 16, p.side = 4))
         RUN_SKW("skinny W8 LN gate (no dw)", 1, 8, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SKW("skinny WM2 WK4 LN gate (no dw)", 2, 4, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SKW("skinny WM4 WK2 LN gate (no dw)", 4, 2, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SKW("skinny WM8 WK1 LN gate (no dw)", 8, 1, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
     }
     if (getenv("CHAIN") && (K == 128 || K == 256) && K == N) {
         // ---- the row-local NAF tail as one kernel (hd_chain.hpp): phase stamps ----
