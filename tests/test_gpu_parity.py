@@ -209,7 +209,10 @@ def test_every_launch_is_reproducible(gpu, weights16):
     no float atomics, and no dependence on how loads and LDS returns happen to be timed: the straight-line K loop once
     failed exactly this, in rows 8j+6 / 8j+7 of one tile in one launch out of tens)."""
     import determinism_scan
-    n, bad = determinism_scan.scan(64, 16, 3, model=make_model(weights16), verbose=False)
+    m = make_model(weights16)
+    n, bad = determinism_scan.scan(64, 16, 3, model=m, verbose=False)
+    assert n > 100 and not bad, bad
+    n, bad = determinism_scan.scan(64, 16, 2, model=m, verbose=False, which=1)      # the conditioning prologue (FPG, IDC, gates)
     assert n > 100 and not bad, bad
 
 

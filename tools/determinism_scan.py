@@ -1,6 +1,6 @@
 """Find the first launch of the denoiser program whose output differs between two identical runs (GPU).
 
-usage: python tools/determinism_scan.py [batch] [latent] [repeats]
+usage: python tools/determinism_scan.py [batch] [latent] [repeats] [which: 0 denoiser, 1 conditioning prologue]
 Every launch is meant to be bitwise reproducible (fixed reduction orders, no float atomics); a launch that is not has a
 race or reads something uninitialised.  Runs the program up to launch i twice (hd_debug_limit_ops) and compares its output.
 """
@@ -12,8 +12,9 @@ from hifidiff_amd import _lib, refiner, synth
 from tools.op_parity import read_op
 
 
-def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5):
-    """Returns (launches scanned, [(index, name, differing values, max abs difference), ...])."""
+def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0):
+    """Returns (launches scanned, [(index, name, differing values, max abs difference), ...]).
+    which = 0: the denoiser program (one eps evaluation); 1: the conditioning prologue (FPG, ResNet-50 IDC, gates)."""
     m = model
     if m is None:
         m = refiner.FacialRefiner(latent)
@@ -24,16 +25,19 @@ def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5):
     e.prepare(crl, cr_face=crf)
     L = _lib.lib()
     t = torch.full((B,), 500.0, device="cuda")
-    n = L.hd_num_ops(e.ctx, 0)
+    n = L.hd_num_ops(e.ctx, which)
     bad = []
     for i in range(n):
-        name = L.hd_debug_op_name(e.ctx, 0, i).decode()
-        L.hd_debug_limit_ops(e.ctx, 0, i + 1)
+        name = L.hd_debug_op_name(e.ctx, which, i).decode()
+        L.hd_debug_limit_ops(e.ctx, which, i + 1)
         outs = []
         for _ in range(reps):
-            e.eps(x, t)
+            if which == 1:
+                e.prepare(crl, cr_face=crf)
+            else:
+                e.eps(x, t)
             torch.cuda.synchronize()
-            outs.append(read_op(L, e.ctx, 0, i).numpy().copy())
+            outs.append(read_op(L, e.ctx, which, i).numpy().copy())
         same = all(np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)) for o in outs[1:])
         if not same:
             d = max(float(np.abs(outs[0] - o).max()) for o in outs[1:])
@@ -43,7 +47,9 @@ def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5):
             bad.append((i, name, nd, d))
             if len(bad) >= max_bad:
                 break
-    L.hd_debug_limit_ops(e.ctx, 0, -1)
+    L.hd_debug_limit_ops(e.ctx, which, -1)
+    if which == 1:
+        e.prepare(crl, cr_face=crf)
     return n, bad
 
 
@@ -51,7 +57,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     latent = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    n, bad = scan(B, latent, reps)
+    which = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    n, bad = scan(B, latent, reps, which=which)
     print(f"{n} launches scanned, {len(bad)} not reproducible")
     return 1 if bad else 0
 
