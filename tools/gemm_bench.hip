@@ -261,7 +261,7 @@ int main(int argc, char** argv) {
         RUN_SKW("skinny WM4 bf16plain resid +stats", 4, 1, 1, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
         RUN_SKW("skinny WM8 bf16plain resid +stats", 8, 1, 1, false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
     }
-    if (M >= 2048) {
+    if (M >= 1024) {
         RUN_TALL("tall T32W bf16plain resid", T32W, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
         RUN_TALL("tall T32W bf16plain resid (no stats)", T32W, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA))
         RUN_TALL("tall T64  bf16plain resid", T64, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
