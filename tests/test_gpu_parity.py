@@ -243,6 +243,30 @@ def test_full_batch_properties(gpu, weights16):
     assert psnr(two.cpu(), full[:2].cpu()) >= 50.0
 
 
+def test_static_and_runtime_k_loops_agree_bitwise(gpu, weights16):
+    """The straight-line K loop (chunk count known at launch, packed LayerNorm transform) is the same arithmetic as the
+    run-time loop it replaced: one eps evaluation of 7 faces gives the same bits with the run-time loop forced in a child
+    process (HD_EXPERIMENTS=1 HD_NO_STATIC_K=1; the switch is read once per process)."""
+    import subprocess
+    import hashlib
+    from hifidiff_amd import synth
+    code = (
+        "import hashlib, torch, sys; sys.path.insert(0, %r)\n"
+        "from hifidiff_amd import synth; from hifidiff_amd.refiner import FacialRefiner\n"
+        "m = FacialRefiner(16); m.load_state_dict(synth.refiner_state_dict(16)); m.to('cuda:0')\n"
+        "x, crl, crf = [t.cuda() for t in synth.sample_inputs(7, 16)]\n"
+        "e = m(x, torch.tensor([980., 500., 0., 37., 861., 250., 999.]), crf, crl).sample\n"
+        "print('EPS', hashlib.sha256(e.cpu().numpy().tobytes()).hexdigest())\n" % ROOT)
+    env = dict(os.environ, HD_EXPERIMENTS="1", HD_NO_STATIC_K="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    child = [l.split()[1] for l in out.stdout.splitlines() if l.startswith("EPS ")][0]
+    m = make_model(weights16)
+    x, crl, crf = [t.cuda() for t in synth.sample_inputs(7, 16)]
+    e = m(x, torch.tensor([980., 500., 0., 37., 861., 250., 999.]), crf, crl).sample
+    assert hashlib.sha256(e.cpu().numpy().tobytes()).hexdigest() == child
+
+
 def test_error_behaviour(gpu, weights16, model2, inputs2):
     from hifidiff_amd.refiner import FacialRefiner
     x, crl, crf = [t.cuda() for t in inputs2]
