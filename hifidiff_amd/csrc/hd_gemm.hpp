@@ -387,7 +387,9 @@ struct LdF32LN_T {
     }
     // K % 64 == 0 (host): no bound to test, the load is not under a branch (rows beyond M re-read row 0 and are zeroed by
     // finish()), so the compiler can count the loads in flight (see gemm_skinny_kernel, CPW)
-    static __device__ __forceinline__ void fetch_nc(const St& st, int kc, int kq, Raw& r) {
+    static constexpr bool kStatic8 = false;
+    static bool static_ok(const GemmP&) { return true; }
+    static __device__ __forceinline__ void fetch_nc(const GemmP&, const St& st, int kc, int kq, Raw& r) {
         r.x = *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq);
     }
     static __device__ __forceinline__ uint4 finish(const GemmP& p, const St& st, int kc, int kq, const Raw& r) {
@@ -479,7 +481,9 @@ struct LdBF16Plain {
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
         r.x = (st.valid && kc + 8 * kq < p.K) ? *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq) : make_uint4(0, 0, 0, 0);
     }
-    static __device__ __forceinline__ void fetch_nc(const St& st, int kc, int kq, Raw& r) {
+    static constexpr bool kStatic8 = false;
+    static bool static_ok(const GemmP&) { return true; }
+    static __device__ __forceinline__ void fetch_nc(const GemmP&, const St& st, int kc, int kq, Raw& r) {
         r.x = *reinterpret_cast<const uint4*>(st.rowp + kc + 8 * kq);
     }
     static __device__ __forceinline__ uint4 finish(const GemmP&, const St& st, int, int, const Raw& r) {
@@ -529,9 +533,26 @@ struct LdBF16Scale {
 template <bool SRC_BF16, bool GATED>
 struct LdConv {
     static constexpr int kRawRegs = (SRC_BF16 ? 4 : 8) + (GATED ? 18 : 0) + 2;
-    static constexpr bool kGainBiasLds = false, kSplit = !SRC_BF16, kStaticK = false;
+    static constexpr bool kGainBiasLds = false, kSplit = !SRC_BF16, kStaticK = SRC_BF16 && !GATED;
     struct St { int b, iy0, ix0; bool valid; };
     struct Raw { float4 x[2]; float4 add[2]; float4 gc[2]; float gs[2]; uint4 xb; bool inb[2]; };
+    // straight-line K loop: every 64-deep chunk lies inside one tap and no tap falls outside the image (the stride-2 2x2
+    // down-convs and the 1x1 convs), so the gather needs no bounds
+    static constexpr bool kStatic8 = true;                      // K = 4096 (8 chunks per wave) occurs: downs.3
+    static bool static_ok(const GemmP& p) {
+        return p.pad == 0 && p.Cin % 64 == 0 && p.ntaps == p.KH * p.KW && p.ntaps * p.Cin == p.K &&
+               (p.Hout - 1) * p.stride + p.KH <= p.Hin && (p.Wout - 1) * p.stride + p.KW <= p.Win;
+    }
+    struct ChunkC {};
+    static __device__ __forceinline__ void chunk_consts(const GemmP&, const St&, int, int, ChunkC&) {}
+    static __device__ __forceinline__ void fetch_nc(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
+        const int k = kc + 8 * kq, tap = k / p.Cin, c0 = k - tap * p.Cin, ky = tap / p.KW;
+        const size_t srow = ((size_t)st.b * p.Hin + st.iy0 + ky) * p.Win + st.ix0 + (tap - ky * p.KW);
+        r.xb = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.A) + srow * p.Cin + c0);
+    }
+    static __device__ __forceinline__ uint4 finish_nc(const GemmP&, const St& st, int, int, const Raw& r, const ChunkC&) {
+        return st.valid ? r.xb : make_uint4(0, 0, 0, 0);
+    }
     struct Pre {};
     template <int BM, int THREADS> static __device__ __forceinline__ void block_issue(const GemmP&, int, float*, int, Pre&) {}
     template <int BM, int THREADS> static __device__ __forceinline__ void block_finish(const GemmP&, int, char*, float*, int, const Pre&) {}
@@ -1170,7 +1191,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_skinny_kernel(const GemmP p) 
     _Pragma("unroll") for (int u = 0; u < UN; ++u)                                                     \
         LD::fetch(p, st[u], ((chunk) < c_end) ? (chunk) * BK : p.Kp, kq, aq[slot][u]);
 #define HD_SK_FETCH_A_NC(slot, chunk) \
-    _Pragma("unroll") for (int u = 0; u < UN; ++u) LD::fetch_nc(st[u], (chunk) * BK, kq, aq[slot][u]);
+    _Pragma("unroll") for (int u = 0; u < UN; ++u) LD::fetch_nc(p, st[u], (chunk) * BK, kq, aq[slot][u]);
     if constexpr (CPW > 0) {                                   // chunk by chunk: loads return in issue order, chunk 0 is needed first
 #pragma unroll
         for (int d = 0; d < (D < CPW ? D : CPW); ++d) { HD_SK_LOAD_B_NC(d, c0 + d); HD_SK_FETCH_A_NC(d, c0 + d); }
@@ -1471,9 +1492,13 @@ inline hipError_t launch_skinny(const GemmP& p, hipStream_t s) {
         static const bool no_static = hd_env("HD_NO_STATIC_K") != nullptr;
         const int cpw = (p.Kp / 64) / C::WK;
         const int ncols = (C::TNT == 2) ? p.N / 2 : p.N;
-        if (!no_static && p.K == p.Kp && ncols % 32 == 0 && (cpw == 2 || cpw == 4)) {
+        const bool ok = !no_static && p.K == p.Kp && ncols % 32 == 0 && LD::static_ok(p);
+        if (ok && (cpw == 2 || cpw == 4)) {
             if (cpw == 4) return nt ? launch_skinny_inst<C, LD, EP, true, 4>(p, s, smem) : launch_skinny_inst<C, LD, EP, false, 4>(p, s, smem);
             return nt ? launch_skinny_inst<C, LD, EP, true, 2>(p, s, smem) : launch_skinny_inst<C, LD, EP, false, 2>(p, s, smem);
+        }
+        if constexpr (LD::kStatic8 && C::WK == 8 && C::MT == 1) {
+            if (ok && cpw == 8) return nt ? launch_skinny_inst<C, LD, EP, true, 8>(p, s, smem) : launch_skinny_inst<C, LD, EP, false, 8>(p, s, smem);
         }
     }
     return nt ? launch_skinny_inst<C, LD, EP, true, 0>(p, s, smem) : launch_skinny_inst<C, LD, EP, false, 0>(p, s, smem);
