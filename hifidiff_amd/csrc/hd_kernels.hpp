@@ -75,20 +75,24 @@ __global__ void intro_weight_layout_kernel(const float* __restrict__ w, float* _
     const int co = i / 36;
     wT[(i - co * 36) * 128 + co] = w[i];
 }
+// PXS: pixels per wave.  One wave per run of 16 pixels gave one wave per SIMD at the benchmark batch (1024 waves): a serial
+// chain of LDS reads, FMAs, DPP reductions and stores with nothing to overlap it; runs of 4 put four waves on a SIMD.
+constexpr int kIntroPx = 8, kEndingPx = 8;
+template <int PXS>
 __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict__ lat, const float* __restrict__ wT,
                                                           const float* __restrict__ b, float* __restrict__ out,
                                                           unsigned short* __restrict__ out16, float2* __restrict__ stats, int B, int L,
                                                           StepState* st, int advance) {
-    __shared__ float patch[4][4][3][20];                                 // [wave][ci][row][x0-1 .. x0+16] (+pad)
+    __shared__ float patch[4][4][3][PXS + 4];                            // [wave][ci][row][x0-1 .. x0+PXS] (+pad)
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nseg = B * L * (L >> 4);
+    const int nseg = B * L * (L / PXS);
     const int seg = blockIdx.x * 4 + wave;
     if (seg >= nseg) return;                                             // whole wave; no block-wide barrier below
-    const int spr = L >> 4;
-    const int bb = seg / (L * spr), rem = seg - bb * L * spr, y = rem / spr, x0 = (rem - y * spr) << 4;
-    for (int i = lane; i < 4 * 3 * 18; i += 64) {
-        const int ci = i / 54, r = (i - ci * 54) / 18, xx = i - ci * 54 - r * 18;
+    const int spr = L / PXS;
+    const int bb = seg / (L * spr), rem = seg - bb * L * spr, y = rem / spr, x0 = (rem - y * spr) * PXS;
+    for (int i = lane; i < 4 * 3 * (PXS + 2); i += 64) {
+        const int ci = i / (3 * (PXS + 2)), r = (i - ci * 3 * (PXS + 2)) / (PXS + 2), xx = i - ci * 3 * (PXS + 2) - r * (PXS + 2);
         const int yy = y + r - 1, x = x0 + xx - 1;
         patch[wave][ci][r][xx] = (yy >= 0 && yy < L && x >= 0 && x < L) ? lat[((size_t)(bb * 4 + ci) * L + yy) * L + x] : 0.f;
     }
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict
     const float b0 = b[lane], b1 = b[lane + 64];
     __builtin_amdgcn_wave_barrier();
     const size_t row0 = ((size_t)bb * L + y) * L + x0;
-#pragma unroll 4
-    for (int px = 0; px < 16; ++px) {
+#pragma unroll
+    for (int px = 0; px < PXS; ++px) {
         float a0 = b0, a1 = b1;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
@@ -154,11 +158,12 @@ __global__ void ending_weight_layout_kernel(const float* __restrict__ w, float* 
     const int co = i / (128 * 9), r = i - co * 128 * 9, ci = r / 9, tap = r - ci * 9;
     wT[(tap * 4 + co) * 128 + ci] = w[i];
 }
+template <int PXS>
 __global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restrict__ X, const float* __restrict__ wT,
                                                            const float* __restrict__ b, float* __restrict__ eps,
                                                            int B, int L, const SchedArgs sa) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nseg = B * L * (L >> 4);                                   // runs of 16 pixels (L is a multiple of 16)
+    const int nseg = B * L * (L / PXS);                                  // runs of PXS pixels (L is a multiple of 16)
     const int nb_conv = (nseg + 3) >> 2;
     if ((int)blockIdx.x >= nb_conv) {
         // trailing workgroups: stage the NEXT step's FiLM row at a fixed address, so that no LayerNorm loader of
@@ -172,8 +177,8 @@ __global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restric
     }
     const int seg = blockIdx.x * 4 + wave;
     if (seg >= nseg) return;                                             // whole wave; no block-wide barrier below
-    const int spr = L >> 4;                                              // runs per image row
-    const int bb = seg / (L * spr), rem = seg - bb * L * spr, y = rem / spr, x0 = (rem - y * spr) << 4;
+    const int spr = L / PXS;                                             // runs per image row
+    const int bb = seg / (L * spr), rem = seg - bb * L * spr, y = rem / spr, x0 = (rem - y * spr) * PXS;
     float wl[9][4][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -197,9 +202,9 @@ __global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restric
     float cl[3][2], cc[3][2], cr[3][2];
     load_col(x0 - 1, cl);
     load_col(x0, cc);
-    float part[16][4];
+    float part[PXS][4];
 #pragma unroll
-    for (int px = 0; px < 16; ++px) {
+    for (int px = 0; px < PXS; ++px) {
         load_col(x0 + px + 1, cr);
 #pragma unroll
         for (int co = 0; co < 4; ++co) {
@@ -215,15 +220,16 @@ __global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 3; ++r) { cl[r][0] = cc[r][0]; cl[r][1] = cc[r][1]; cc[r][0] = cr[r][0]; cc[r][1] = cr[r][1]; }
     }
-    // wave reduction of the 64 partial sums; lane j keeps value j = (pixel j >> 2, output j & 3)
+    // wave reduction of the 4 PXS partial sums; lane j keeps value j = (pixel j >> 2, output j & 3)
     float mine = 0.f;
 #pragma unroll
-    for (int px = 0; px < 16; ++px)
+    for (int px = 0; px < PXS; ++px)
 #pragma unroll
         for (int co = 0; co < 4; ++co) {
             const float t = wave_sum(part[px][co]);
             if (lane == px * 4 + co) mine = t;
         }
+    if (lane >= 4 * PXS) return;
     const int co = lane & 3, x = x0 + (lane >> 2);
     const size_t o = (((size_t)bb * 4 + co) * L + y) * L + x;           // NCHW
     const float e = mine + b[co];
