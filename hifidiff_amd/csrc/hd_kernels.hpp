@@ -76,8 +76,10 @@ __global__ void intro_weight_layout_kernel(const float* __restrict__ w, float* _
     wT[(i - co * 36) * 128 + co] = w[i];
 }
 // PXS: pixels per wave.  One wave per run of 16 pixels gave one wave per SIMD at the benchmark batch (1024 waves): a serial
-// chain of LDS reads, FMAs, DPP reductions and stores with nothing to overlap it; runs of 4 put four waves on a SIMD.
-constexpr int kIntroPx = 8, kEndingPx = 8;
+// chain of LDS reads, FMAs, DPP reductions and stores with nothing to overlap it; runs of 8 put two waves on a SIMD
+// (measured per launch, runs of 16 / 8 / 4 / 2: intro 13.4 / 9.5 / 9.5 / 10.8 us, ending 11.8 / 8.8 / 9.8 / 12.8 us).  From
+// kLongRunRows rows on (latent 32 at batch 64) runs of 16 already give four waves per SIMD and re-read fewer halo columns.
+constexpr int kIntroPx = 8, kEndingPx = 8, kLongRunRows = 32768;
 template <int PXS>
 __global__ __launch_bounds__(256) void intro_conv_kernel(const float* __restrict__ lat, const float* __restrict__ wT,
                                                           const float* __restrict__ b, float* __restrict__ out,

@@ -1147,7 +1147,8 @@ int build_denoiser_program(hd_ctx* c) {
         unsigned short* xb = c->ch->lv[0].Xb;
         const int M = c->ch->lv[0].M;
         prog.push_back({"intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel<kIntroPx>, dim3((M / kIntroPx + 3) / 4), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
+                            if (M >= kLongRunRows) hipLaunchKernelGGL(intro_conv_kernel<16>, dim3((M / 16 + 3) / 4), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
+                            else hipLaunchKernelGGL(intro_conv_kernel<kIntroPx>, dim3((M / kIntroPx + 3) / 4), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
@@ -1216,7 +1217,8 @@ int build_denoiser_program(hd_ctx* c) {
                             // sampling loop (film_from_cur): the launch also applies the scheduler update to this
                             // chain's latents and stages the next step's FiLM row
                             SchedArgs sa{};
-                            unsigned nb = (unsigned)((M / kEndingPx + 3) / 4);
+                            const bool long_runs = M >= kLongRunRows;
+                            unsigned nb = (unsigned)((M / (long_runs ? 16 : kEndingPx) + 3) / 4);
                             if (c->film_from_cur) {
                                 const size_t per_face = (size_t)4 * L * L;
                                 sa.lat = chp->lat; sa.coef = c->coef_dev; sa.st = chp->step_state;
@@ -1224,7 +1226,8 @@ int build_denoiser_program(hd_ctx* c) {
                                 sa.film_table = c->film_table; sa.film_cur = chp->film_cur; sa.film_total = c->film_total;
                                 nb += (unsigned)((c->film_total / 4 + 255) / 256);
                             }
-                            hipLaunchKernelGGL(ending_conv_kernel<kEndingPx>, dim3(nb), dim3(256), 0, s, X, w, b, eps, B, L, sa);
+                            if (long_runs) hipLaunchKernelGGL(ending_conv_kernel<16>, dim3(nb), dim3(256), 0, s, X, w, b, eps, B, L, sa);
+                            else hipLaunchKernelGGL(ending_conv_kernel<kEndingPx>, dim3(nb), dim3(256), 0, s, X, w, b, eps, B, L, sa);
                             return hipGetLastError();
                         }});
         prog.back().out = eps; prog.back().out_elems = (size_t)B * 4 * L * L;
@@ -1273,7 +1276,8 @@ void add_fpg(hd_ctx* c, std::vector<Op>& prog, const float* cr_latent_dev) {
         unsigned short* xb = c->ch->lv[0].Xb;
         Chain* chp = c->ch;
         prog.push_back({"fpg.intro", [=](hipStream_t s) -> hipError_t {
-                            hipLaunchKernelGGL(intro_conv_kernel<kIntroPx>, dim3((M / kIntroPx + 3) / 4), dim3(256), 0, s, cr_latent_dev, w, b, out, xb, sx, B, L, chp->step_state, 0);
+                            if (M >= kLongRunRows) hipLaunchKernelGGL(intro_conv_kernel<16>, dim3((M / 16 + 3) / 4), dim3(256), 0, s, cr_latent_dev, w, b, out, xb, sx, B, L, chp->step_state, 0);
+                            else hipLaunchKernelGGL(intro_conv_kernel<kIntroPx>, dim3((M / kIntroPx + 3) / 4), dim3(256), 0, s, cr_latent_dev, w, b, out, xb, sx, B, L, chp->step_state, 0);
                             return hipGetLastError();
                         }});
         prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
