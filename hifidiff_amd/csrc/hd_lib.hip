@@ -553,7 +553,9 @@ int choose_mode(const GemmP& p, bool pair) {
     // 64-row tiles halve the weight re-reads; with a short K (<= 512) and a grid that would only just fill the chip,
     // 32-row tiles (twice the workgroups, two per CU) hide more latency (level 2: conv3/conv5 7.7 -> 6.3 us)
     const int wg64 = ((p.M + 63) / 64) * nb32;
-    if (wg64 >= 192 && (p.Kp > 512 || wg64 >= 512)) return 2;
+    // (up-convs 2 / 3 and down-conv 0, K <= 512 at 512-1024 such workgroups: 32-row tiles 11.4 / 8.6 / 8.4 us against 14.4 / 10.2 / 9.4)
+    static const int short_k_wg = hd_env("HD_SHORTK_WG") ? atoi(hd_env("HD_SHORTK_WG")) : 2048;
+    if (wg64 >= 192 && (p.Kp > 512 || wg64 >= short_k_wg)) return 2;
     return 3;
 }
 
