@@ -210,7 +210,9 @@ def test_every_launch_is_reproducible(gpu, weights16):
     failed exactly this, in rows 8j+6 / 8j+7 of one tile in one launch out of tens)."""
     import determinism_scan
     m = make_model(weights16)
-    n, bad = determinism_scan.scan(64, 16, 3, model=m, verbose=False)
+    n, bad = determinism_scan.scan(64, 16, 3, model=m, verbose=False, per_face=False)   # one timestep for all faces: the sampling loop's kernels
+    assert n > 100 and not bad, bad
+    n, bad = determinism_scan.scan(64, 16, 3, model=m, verbose=False, per_face=True)    # a timestep per face: the LdF32LNFace kernels
     assert n > 100 and not bad, bad
     n, bad = determinism_scan.scan(64, 16, 2, model=m, verbose=False, which=1)      # the conditioning prologue (FPG, IDC, gates)
     assert n > 100 and not bad, bad

@@ -1,6 +1,6 @@
 """Find the first launch of the denoiser program whose output differs between two identical runs (GPU).
 
-usage: python tools/determinism_scan.py [batch] [latent] [repeats] [which: 0 denoiser, 1 conditioning prologue]
+usage: python tools/determinism_scan.py [batch] [latent] [repeats] [which: 0 denoiser, 1 conditioning prologue] [per-face timesteps: 1 / 0]
 Every launch is meant to be bitwise reproducible (fixed reduction orders, no float atomics); a launch that is not has a
 race or reads something uninitialised.  Runs the program up to launch i twice (hd_debug_limit_ops) and compares its output.
 """
@@ -12,9 +12,11 @@ from hifidiff_amd import _lib, refiner, synth
 from tools.op_parity import read_op
 
 
-def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0):
+def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0, per_face=True):
     """Returns (launches scanned, [(index, name, differing values, max abs difference), ...]).
-    which = 0: the denoiser program (one eps evaluation); 1: the conditioning prologue (FPG, ResNet-50 IDC, gates)."""
+    which = 0: the denoiser program (one eps evaluation); 1: the conditioning prologue (FPG, ResNet-50 IDC, gates).
+    per_face: a timestep per face (the LayerNorm GEMMs read FiLM rows of the global table: LdF32LNFace) or one for all faces
+    (the sampling loop's form: the shared row copied to LDS, LdF32LN) -- different kernels."""
     m = model
     if m is None:
         m = refiner.FacialRefiner(latent)
@@ -24,7 +26,7 @@ def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0):
     e = m.engine
     e.prepare(crl, cr_face=crf)
     L = _lib.lib()
-    t = torch.full((B,), 500.0, device="cuda")
+    t = torch.full((B,), 500.0, device="cuda") if per_face else 500.0
     n = L.hd_num_ops(e.ctx, which)
     bad = []
     for i in range(n):
@@ -58,7 +60,8 @@ def main():
     latent = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     which = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    n, bad = scan(B, latent, reps, which=which)
+    per_face = (int(sys.argv[5]) != 0) if len(sys.argv) > 5 else True
+    n, bad = scan(B, latent, reps, which=which, per_face=per_face)
     print(f"{n} launches scanned, {len(bad)} not reproducible")
     return 1 if bad else 0
 
