@@ -370,15 +370,15 @@ struct LdF32LN_T {
     }
     static __device__ __forceinline__ void unit_stats(St& st, int row_local, const char* stats) {
         float2 s = reinterpret_cast<const float2*>(stats)[row_local];
-        // The row statistics are read once and live in registers for the whole K loop.  In the straight-line K loop the
-        // compiler batches this read with the first gain / bias reads and resumes on a partial count (s_waitcnt
-        // lgkmcnt(5)) with the multiply below as the next instruction; in that form rows 8j+6 / 8j+7 of a tile (lanes
-        // 48-63 of a unit) came out different in >= 1 launch of 60 on MI355X, and only when the transform used these
-        // values (constants instead: reproducible).  Consuming the read here behind a full wait gives 0 of 5400 launches
-        // (tools/det_bench).  The cause is not established: checks of the ordering rules this could have broken -- vector
-        // loads and LDS returns against their counters, a 128-bit LDS store against the VALU write before it and the LDS
-        // load after it, an MFMA whose D overlaps its A / B -- all came back clean (tools/vmorder_bench, ldswar_bench,
-        // mfma_overlap_bench).  tests/test_gpu_parity.py::test_every_launch_is_reproducible guards it.
+        // The row statistics are read once and live in registers for the whole K loop.  In the straight-line K loop, without
+        // the statement below, rows 8j+6 / 8j+7 of a tile (lanes 48-63 of a unit) came out different in >= 1 launch of 60 on
+        // MI355X, and only when the transform used these values (constants instead: reproducible).  With it: 0 of 5400
+        // launches (tools/det_bench).  The cause is not established.  It is not the wait as such -- the kernel built with
+        // every compiler wait forced to zero still differs -- but how the code around the first use is laid out: the asm makes
+        // the two values opaque, so they are consumed here and kept in registers of their own instead of being read, with
+        // op_sel, out of the pair the LDS read delivered.  Checks of the hardware rules this could have broken all came back
+        // clean (tools/vmorder_bench, ldswar_bench, mfma_overlap_bench, pkfma_bench).
+        // tests/test_gpu_parity.py::test_every_launch_is_reproducible guards it.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(s.x), "+v"(s.y));
         st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
     }
