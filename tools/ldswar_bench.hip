@@ -118,6 +118,44 @@ __global__ __launch_bounds__(512) void xwave_kernel(unsigned* bad, unsigned* bad
     if (nbad) atomicAdd(bad, nbad);
 }
 
+// mode 4: the address register of LDS reads overwritten by the next VALU instruction (what the compiler emitted right after the
+// reads of the row statistics: ds_read2_b64 .., v37 ..; ds_read2_b64 .., v37 ..; v_lshrrev_b32 v37, ..).
+template <int GAP>
+__global__ __launch_bounds__(512) void addr_war_kernel(unsigned* bad, unsigned* bad_lane_hist, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned* ent = reinterpret_cast<unsigned*>(xsmem + 69632);
+    for (int i = tid; i < 64; i += 512) ent[i] = 0x1000u + (unsigned)i;      // entry e = (0x1000 + 2e, 0x1001 + 2e)
+    unsigned* table = reinterpret_cast<unsigned*>(xsmem + 70000 + 1024);
+    for (int i = tid; i < 1024; i += 512) table[i] = 0xAAAAAAAAu;
+    __syncthreads();
+    unsigned nbad = 0;
+    for (int it = 0; it < iters; ++it) {
+        unsigned rd = 69632 + (unsigned)(lane >> 3) * 8;
+        const unsigned tb = 70000 + 1024 + (lane & 7) * 32;
+        unsigned a0, a1, b0, b1, c0, c1, d0, d1;
+        asm volatile(
+            "s_barrier\n\t"
+            "ds_read2_b64 v[42:45], %8 offset1:8\n\t"
+            "ds_read2_b64 v[46:49], %8 offset0:16 offset1:24\n\t"
+            ".rept %c10\n\ts_nop 0\n\t.endr\n\t"
+            "v_lshrrev_b32 %8, 5, %8\n\t"                         // the address register is dead for the program: reuse it
+            "ds_read2_b64 v[50:53], %9 offset1:1\n\t"
+            "ds_read2_b64 v[54:57], %9 offset0:2 offset1:3\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mov_b32 %0, v42\n\tv_mov_b32 %1, v43\n\tv_mov_b32 %2, v44\n\tv_mov_b32 %3, v45\n\t"
+            "v_mov_b32 %4, v46\n\tv_mov_b32 %5, v47\n\tv_mov_b32 %6, v48\n\tv_mov_b32 %7, v49"
+            : "=v"(a0), "=v"(a1), "=v"(b0), "=v"(b1), "=v"(c0), "=v"(c1), "=v"(d0), "=v"(d1), "+v"(rd)
+            : "v"(tb), "n"(GAP)
+            : "memory", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+        const unsigned e = (unsigned)(lane >> 3);
+        const bool ok = a0 == 0x1000u + 2 * e && a1 == 0x1001u + 2 * e && b0 == 0x1000u + 2 * (e + 8) && b1 == 0x1001u + 2 * (e + 8) &&
+                        c0 == 0x1000u + 2 * (e + 16) && c1 == 0x1001u + 2 * (e + 16) && d0 == 0x1000u + 2 * (e + 24) && d1 == 0x1001u + 2 * (e + 24);
+        if (!ok) { ++nbad; atomicAdd(&bad_lane_hist[lane], 1u); }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 int main() {
     unsigned *bad, *hist;
     CK(hipMalloc(&bad, 4)); CK(hipMalloc(&hist, 256));
@@ -139,6 +177,18 @@ int main() {
         CK(hipDeviceSynchronize());
         unsigned h, hl[64]; CK(hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl, hist, 256, hipMemcpyDeviceToHost));
         printf("mode 3 (cross-wave write, barrier, ds_read2_b64, lgkmcnt(5), use): %u bad reads of %u", h, 1024u * 512u * 4000u);
+        if (h) { printf("; by lane:"); for (int l = 0; l < 64; ++l) if (hl[l]) printf(" %d:%u", l, hl[l]); }
+        printf("\n");
+    }
+    for (int gap = 0; gap < 2; ++gap) {
+        CK(hipMemset(bad, 0, 4)); CK(hipMemset(hist, 0, 256));
+        if (gap == 0) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&addr_war_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        hipLaunchKernelGGL(addr_war_kernel<0>, dim3(1024), dim3(512), 86272, 0, bad, hist, 4000); }
+        else { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&addr_war_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+               hipLaunchKernelGGL(addr_war_kernel<4>, dim3(1024), dim3(512), 86272, 0, bad, hist, 4000); }
+        CK(hipDeviceSynchronize());
+        unsigned h, hl[64]; CK(hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl, hist, 256, hipMemcpyDeviceToHost));
+        printf("mode 4 (address VGPR of two ds_read2_b64 overwritten by the next VALU instruction%s): %u bad reads of %u", gap ? ", 4 idle cycles between" : "", h, 1024u * 512u * 4000u);
         if (h) { printf("; by lane:"); for (int l = 0; l < 64; ++l) if (hl[l]) printf(" %d:%u", l, hl[l]); }
         printf("\n");
     }
