@@ -80,10 +80,25 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
     {
         constexpr int PPR = C / 8;                                 // pieces per pixel
         const uint4* src = reinterpret_cast<const uint4*>(p.X + (size_t)pix0 * C);
-        for (int i = tid; i < K::NP * PPR; i += K::THREADS) {
-            const int px = i / PPR, q = i - px * PPR;
-            const uint4 v = (pix0 + px < p.M) ? src[i] : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(smem + px * K::ROWB + q * 16) = v;
+        // all loads first, then all LDS stores: written as one loop the compiler kept it rolled, one load -> wait -> store
+        // per trip, i.e. eight serial round trips ahead of the first MFMA (6 of the kernel's 12 us).  The address is clamped
+        // and the value masked instead of the load being predicated, so that nothing sits under a branch.
+        constexpr int NIT = (K::NP * PPR + K::THREADS - 1) / K::THREADS;
+        static_assert(NIT <= 16, "staging registers");
+        uint4 stage[NIT];
+        const int last = (p.M - pix0) * PPR - 1;                   // last valid piece of this workgroup's faces (>= 0: row0 < M)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * K::THREADS;
+            stage[it] = src[i <= last ? i : last];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * K::THREADS;
+            if ((K::NP * PPR) % K::THREADS == 0 || i < K::NP * PPR) {
+                const int px = i / PPR, q = i - px * PPR;
+                *reinterpret_cast<uint4*>(smem + px * K::ROWB + q * 16) = i <= last ? stage[it] : make_uint4(0, 0, 0, 0);
+            }
         }
         for (int i = tid; i < K::ROWB / 16; i += K::THREADS) *reinterpret_cast<uint4*>(smem + K::NP * K::ROWB + i * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -121,7 +136,12 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
         const bf16x8_t b = __builtin_bit_cast(bf16x8_t, bq[n % K::DEPTH]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
-        if (n + K::DEPTH < K::NSTEP) bq[n % K::DEPTH] = HD_CONV_B(n + K::DEPTH);
+        if (n + K::DEPTH < K::NSTEP) {
+            bq[n % K::DEPTH] = HD_CONV_B(n + K::DEPTH);
+            // keep the refill HERE: left to itself the scheduler sinks it to just before its use DEPTH steps later (shorter
+            // live range), i.e. issues it and waits for it at once -- a ring of depth 1-2 instead of DEPTH
+            asm volatile("" ::: "memory");
+        }
     }
 #undef HD_CONV_B
 
