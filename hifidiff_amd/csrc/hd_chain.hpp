@@ -111,16 +111,19 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
     }
     // ---- SCA: s = Wsca * pooled[face] + b on the MFMA (row 0 of the A tile holds the pooled vector) ----
     {
+        // the pooled vector goes through LDS (the y tile is free until conv3's epilogue).  Read from global memory by the two
+        // lanes that hold row 0, under a branch, it was 16 load -> wait -> pack round trips in a row: most of this phase.
+        float* pl = yt;
         const float* pv = p.pooled + (size_t)face * C;
+        for (int k = tid; k < C; k += K::THREADS) pl[k] = pv[k];
+        __syncthreads();
         uint4 a[K::KS];
 #pragma unroll
         for (int ks = 0; ks < K::KS; ++ks) {
-            a[ks] = make_uint4(0, 0, 0, 0);
-            if ((lane & 31) == 0) {
-                const float* q = pv + ks * 16 + 8 * (lane >> 5);
-                const float4 v0 = *reinterpret_cast<const float4*>(q), v1 = *reinterpret_cast<const float4*>(q + 4);
-                a[ks] = make_uint4(pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w));
-            }
+            const float* q = pl + ks * 16 + 8 * (lane >> 5);              // LDS, same address for the 32 lanes of a half-wave
+            const float4 v0 = *reinterpret_cast<const float4*>(q), v1 = *reinterpret_cast<const float4*>(q + 4);
+            const uint4 row0 = make_uint4(pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w));
+            a[ks] = (lane & 31) == 0 ? row0 : make_uint4(0, 0, 0, 0);
         }
         f32x16_t acc;
 #pragma unroll
