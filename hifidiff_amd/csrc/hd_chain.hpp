@@ -109,6 +109,22 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
         const float* f = p.film + (size_t)step * p.film_step_stride + (size_t)(p.face0 + face) * p.film_face_stride;
         for (int k = tid; k < C; k += K::THREADS) { gb[k] = f[p.film_gain_off + k]; gb[C + k] = f[p.film_bias_off + k]; }
     }
+    // per-column constants of all four GEMM epilogues: requested now.  Read at the top of each epilogue they were a dependent
+    // round trip per phase (the barriers keep the compiler from hoisting them)
+    const float c_bsca = p.bsca[col], c_b3 = p.b3[col], c_beta = p.beta[col], c_b4a = p.b4[col], c_b4b = p.b4[col + C], c_b5 = p.b5[col],
+                c_gamma = p.gamma[col];
+    // the gate tile G of this workgroup's rows (scaled by s and staged after the SCA phase): requested now, with the weights,
+    // not after the phase's barrier (one more dependent round trip there); rows beyond M re-read row0 and are zeroed later
+    constexpr int kGIt = K::BM * (C / 8) / K::THREADS;
+    static_assert(kGIt * K::THREADS == K::BM * (C / 8), "G tile / threads");
+    uint4 gx[kGIt];
+#pragma unroll
+    for (int it = 0; it < kGIt; ++it) {
+        const int u = tid + it * K::THREADS;
+        const int rl = u / (C / 8), kq = u - rl * (C / 8);
+        const int row = (full || row0 + rl < p.M) ? row0 + rl : row0;
+        gx[it] = *reinterpret_cast<const uint4*>(p.G + (size_t)row * C + kq * 8);
+    }
     // ---- SCA: s = Wsca * pooled[face] + b on the MFMA (row 0 of the A tile holds the pooled vector) ----
     {
         // the pooled vector goes through LDS (the y tile is free until conv3's epilogue).  Read from global memory by the two
@@ -131,7 +147,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
 #pragma unroll
         for (int ks = 0; ks < K::KS; ++ks)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ks]), __builtin_bit_cast(bf16x8_t, bw[ks]), acc, 0, 0, 0);
-        if (lane < 32) s_vec[col] = acc[0] + p.bsca[col];          // C/D row 0 = reg 0 of lanes 0..31
+        if (lane < 32) s_vec[col] = acc[0] + c_bsca;               // C/D row 0 = reg 0 of lanes 0..31
     }
     chain_load_b<C>(p.W4, tile, lane, bw);                         // conv4's first gate half flies during the staging and conv3
     // residual x for this wave's tile (needed by the conv3 epilogue): request it now as well
@@ -149,18 +165,14 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
     // ---- A1 = bf16(G * s): 32 rows x C, whole 128-byte lines ----
     {
         char* sA = smem + K::A1_OFF;
-        for (int u = tid; u < K::BM * (C / 8); u += K::THREADS) {
-            const int rl = u / (C / 8), kq = u - rl * (C / 8);
-            const int row = row0 + rl;
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (full || row < p.M) {
-                x = *reinterpret_cast<const uint4*>(p.G + (size_t)row * C + kq * 8);
-                float v[8]; unpack8(x, v);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] *= s_vec[kq * 8 + i];
-                x = pack8(v);
-            }
-            *reinterpret_cast<uint4*>(sA + rl * K::AROW + kq * 16) = x;
+        for (int it = 0; it < kGIt; ++it) {                            // G was requested before the SCA phase (gx)
+            const int u = tid + it * K::THREADS;
+            const int rl = u / (C / 8), kq = u - rl * (C / 8);
+            float v[8]; unpack8(gx[it], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= s_vec[kq * 8 + i];
+            *reinterpret_cast<uint4*>(sA + rl * K::AROW + kq * 16) = (full || row0 + rl < p.M) ? pack8(v) : make_uint4(0, 0, 0, 0);
         }
     }
     __syncthreads();
@@ -171,7 +183,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
         f32x16_t acc[MT];
         chain_mma<C, MT>(smem + K::A1_OFF, bw2, lane, acc);
         chain_load_b<C>(p.W4, tile + K::NT, lane, bw2);            // second gate half, now that conv3 has consumed its registers
-        const float bb = p.b3[col], be = p.beta[col];
+        const float bb = c_b3, be = c_beta;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -222,7 +234,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
         chain_mma<C, MT>(smem + K::A2_OFF, bw2, lane, acc2);
         chain_load_b<C>(p.W5, tile, lane, bw);                     // conv5 weights
         char* sA = smem + K::A1_OFF;
-        const float b1 = p.b4[col], b2 = p.b4[col + C];
+        const float b1 = c_b4a, b2 = c_b4b;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -238,7 +250,7 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
     {
         f32x16_t accs[MT];
         chain_mma<C, MT>(smem + K::A1_OFF, bw, lane, accs);
-        const float bb = p.b5[col], ga = p.gamma[col];
+        const float bb = c_b5, ga = c_gamma;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x16_t& acc = accs[mt];
