@@ -198,6 +198,15 @@ int main(int argc, char** argv) {
           const int nwg = ((M + CFG::BM - 1) / CFG::BM) * ((nc + CFG::NCOLS - 1) / CFG::NCOLS);          \
           report_stamps(stamps, nwg < 8192 ? nwg : 8192); }                                              \
     }
+#define RUN_SKH(name, D, LD, EP, setup)                                                                  \
+    {                                                                                                    \
+        float us = time_it([&](int i) { GemmP p = base(i); setup; hipError_t e = launch_skinny<SkinnyCfg<1, 8, 1, true, D, true>, LD, EP>(p, s); if (e != hipSuccess) { printf("launch failed %s\n", hipGetErrorString(e)); exit(1);} }, iters, s); \
+        printf("%-44s %8.2f us", name, us);                                                             \
+        { GemmP p = base(7); setup; p.stamps = stamps; CK(hipMemsetAsync(stamps, 0, 8192 * 64, s));     \
+          (void)launch_skinny<SkinnyCfg<1, 8, 1, true, D, true>, LD, EP>(p, s); CK(hipStreamSynchronize(s)); \
+          const int nwg = ((M + 15) / 16) * (N / 2 / 32);                                               \
+          report_stamps(stamps, nwg < 8192 ? nwg : 8192); }                                              \
+    }
 #define RUN_SKW(name, WM, WK, MT, PAIR, D, LD, EP, setup)                                                 \
     {                                                                                                    \
         float us = time_it([&](int i) { GemmP p = base(i); setup; hipError_t e = launch_skinny<SkinnyCfg<WM, WK, MT, PAIR, D>, LD, EP>(p, s); if (e != hipSuccess) { printf("launch failed %s\n", hipGetErrorString(e)); exit(1);} }, iters, s); \
@@ -213,6 +222,9 @@ int main(int argc, char** argv) {
         RUN_SKW("skinny W8 LN dwgate hw4 (L3 conv1 fused)", 1, 8, 1, true, 2, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = 4, p.side = 2))
         RUN_SKW("skinny W8 LN dwgate hw16 (L2 conv1 fused)", 1, 8, 1, true, 2, LdF32LN, EpDwGate, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2, p.dw_w = dww, p.dw_b = b.bias, p.pooled = pooled, p.hw = 16, p.side = 4))
         RUN_SKW("skinny W8 LN gate (no dw)", 1, 8, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SKH("skinny W8 LN gate 16-row tiles D2", 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SKH("skinny W8 LN gate 16-row tiles D3", 3, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SKH("skinny W8 LN gate 16-row tiles D4", 4, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SKW("skinny WM2 WK4 LN gate (no dw)", 2, 4, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SKW("skinny WM4 WK2 LN gate (no dw)", 4, 2, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SKW("skinny WM8 WK1 LN gate (no dw)", 8, 1, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
