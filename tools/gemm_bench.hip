@@ -1,7 +1,8 @@
 // gemm_bench.hip — microbenchmark of the GEMM kernel variants on the refiner's shapes (tools only).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gpurun_out/gemm_bench tools/gemm_bench.hip
 // Each variant is launched back to back on one stream over a rotation of weight buffers larger than the
-// 256 MiB Infinity Cache, so weights come from HBM as in the real step.
+// 256 MiB Infinity Cache, so weights come from HBM as in the real step.  XCD=1 uses the library's block -> tile map (row groups of a
+// weight tile on one XCD), which is what the denoiser GEMMs run with; CHAIN=1 M C C benchmarks the chain kernel.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -106,6 +107,7 @@ int main(int argc, char** argv) {
         p.M = M; p.N = N; p.K = K; p.Kp = K; p.nt_total = N / 32; p.W = b.W[getenv("NOROT") ? 0 : i % nrot];
         p.a_scale = 1.f; p.hw = 1; p.ln_eps = 1e-6f; p.shuffle_r = 1; p.stats_np = NP; p.stats_cnt = K / NP;
         p.bias = b.bias; p.rscale = b.rscale; p.resid = b.resid; p.ldr = N; p.out = b.out; p.ldo = N;
+        p.xcd_tile_affine = getenv("XCD") ? 1 : 0;      // XCD=1: the library's block -> tile map (row groups of a weight tile on one XCD)
         return p;
     };
     printf("M=%d K=%d N=%d  weights %.1f MB, rotation %d buffers\n", M, K, N, wbytes / 1e6, nrot);
