@@ -200,15 +200,16 @@ int main(int argc, char** argv) {
           const int nwg = ((M + CFG::BM - 1) / CFG::BM) * ((nc + CFG::NCOLS - 1) / CFG::NCOLS);          \
           report_stamps(stamps, nwg < 8192 ? nwg : 8192); }                                              \
     }
-#define RUN_SKH(name, D, LD, EP, setup)                                                                  \
+#define RUN_SKH2(name, PAIR, D, LD, EP, setup)                                                                  \
     {                                                                                                    \
-        float us = time_it([&](int i) { GemmP p = base(i); setup; hipError_t e = launch_skinny<SkinnyCfg<1, 8, 1, true, D, true>, LD, EP>(p, s); if (e != hipSuccess) { printf("launch failed %s\n", hipGetErrorString(e)); exit(1);} }, iters, s); \
+        float us = time_it([&](int i) { GemmP p = base(i); setup; hipError_t e = launch_skinny<SkinnyCfg<1, 8, 1, PAIR, D, true>, LD, EP>(p, s); if (e != hipSuccess) { printf("launch failed %s\n", hipGetErrorString(e)); exit(1);} }, iters, s); \
         printf("%-44s %8.2f us", name, us);                                                             \
         { GemmP p = base(7); setup; p.stamps = stamps; CK(hipMemsetAsync(stamps, 0, 8192 * 64, s));     \
-          (void)launch_skinny<SkinnyCfg<1, 8, 1, true, D, true>, LD, EP>(p, s); CK(hipStreamSynchronize(s)); \
-          const int nwg = ((M + 15) / 16) * (N / 2 / 32);                                               \
+          (void)launch_skinny<SkinnyCfg<1, 8, 1, PAIR, D, true>, LD, EP>(p, s); CK(hipStreamSynchronize(s)); \
+          const int nwg = ((M + 15) / 16) * (((PAIR) ? N / 2 : N) / 32);                                               \
           report_stamps(stamps, nwg < 8192 ? nwg : 8192); }                                              \
     }
+#define RUN_SKH(name, D, LD, EP, setup) RUN_SKH2(name, true, D, LD, EP, setup)
 #define RUN_SKW(name, WM, WK, MT, PAIR, D, LD, EP, setup)                                                 \
     {                                                                                                    \
         float us = time_it([&](int i) { GemmP p = base(i); setup; hipError_t e = launch_skinny<SkinnyCfg<WM, WK, MT, PAIR, D>, LD, EP>(p, s); if (e != hipSuccess) { printf("launch failed %s\n", hipGetErrorString(e)); exit(1);} }, iters, s); \
@@ -227,6 +228,9 @@ int main(int argc, char** argv) {
         RUN_SKH("skinny W8 LN gate 16-row tiles D2", 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SKH("skinny W8 LN gate 16-row tiles D3", 3, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SKH("skinny W8 LN gate 16-row tiles D4", 4, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
+        RUN_SKH2("skinny W8 bf16plain resid 16-row tiles D2", false, 2, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
+        RUN_SKH2("skinny W8 bf16plain resid 16-row tiles D3", false, 3, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
+        RUN_SKH2("skinny W8 bf16plain resid 16-row tiles D4", false, 4, LdBF16Plain, EpResidF32, (p.A = Ab, p.lda = LDA, p.stats_out = b.stats_out))
         RUN_SKW("skinny WM2 WK4 LN gate (no dw)", 2, 4, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SKW("skinny WM4 WK2 LN gate (no dw)", 4, 2, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
         RUN_SKW("skinny WM8 WK1 LN gate (no dw)", 8, 1, 1, true, 2, LdF32LN, EpGateBF16, (p.A = Ab, p.lda = LDA, p.film = b.film, p.film_gain_off = 0, p.film_bias_off = K, p.stats_in = b.stats_in, p.out = b.outb, p.ldo = N / 2))
