@@ -2261,6 +2261,8 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
         if (rc) return rc;
         c->coef_cap = n;
         c->graphs_valid = false;
+        // parked workspaces captured the old coefficient buffer into their ending launch as well (SchedArgs::coef)
+        for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
     }
     const size_t per_face = (size_t)4 * c->L * c->L;
     const size_t nlat = (size_t)c->B * per_face;
