@@ -31,6 +31,11 @@
 
 #include <stdlib.h>
 
+// No implicit fused multiply-add in this file: whether `a * b + c` becomes one v_fma_f32 is otherwise decided per
+// instantiation (the same epilogue gave different low bits in two tile shapes), and the XCD-local persistent stages
+// (hd_xcd.hpp) must reproduce these kernels bit for bit.  Every fused operation below is written out (fmaf).
+#pragma clang fp contract(off)
+
 namespace hd {
 
 // Tile-shape and fusion rules are FIXED in the product.  The HD_* experiment switches that were used to measure them
@@ -663,7 +668,7 @@ struct EpResidF32 {
         return reinterpret_cast<const float*>(p.resid)[(size_t)row * p.ldr + col];
     }
     static __device__ __forceinline__ float store(const GemmP& p, int row, int col, float v, float r, const ColC& c) {
-        v = r + (v + c.bias) * c.rscale;
+        v = fmaf(v + c.bias, c.rscale, r);
         reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
         if (p.out16) p.out16[(size_t)row * p.ldo + col] = f32_to_bf16_bits(v);
         if (p.outg16) {                                       // f_d * (1 + w_c + w_s) (+ idc term) for the following HCA
@@ -785,7 +790,7 @@ constexpr int kStatLane = 16;
 __device__ __forceinline__ float2 halfwave_mean_m2(float v) {
     const float s1 = halfwave_sum_hi(v), s2 = halfwave_sum_hi(v * v);
     const float mean = s1 * (1.0f / 32.0f);
-    return make_float2(mean, fmaxf(s2 - s1 * mean, 0.f));
+    return make_float2(mean, fmaxf(fmaf(-s1, mean, s2), 0.f));
 }
 
 // Epilogue of one 32x32 accumulator tile in MFMA layout (col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)).
@@ -1040,9 +1045,9 @@ __device__ __forceinline__ float dw_gate_row(const float* t1a, const float* t1b,
     for (int x = 0; x < S; ++x) {
         float u1 = ba, u2 = bb;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            u1 += wa[r * 3] * va[r][x] + wa[r * 3 + 1] * va[r][x + 1] + wa[r * 3 + 2] * va[r][x + 2];
-            u2 += wb[r * 3] * vb[r][x] + wb[r * 3 + 1] * vb[r][x + 1] + wb[r * 3 + 2] * vb[r][x + 2];
+        for (int r = 0; r < 3; ++r) {                                        // nine taps, one fused multiply-add each, in tap order
+            u1 = fmaf(wa[r * 3], va[r][x], u1); u1 = fmaf(wa[r * 3 + 1], va[r][x + 1], u1); u1 = fmaf(wa[r * 3 + 2], va[r][x + 2], u1);
+            u2 = fmaf(wb[r * 3], vb[r][x], u2); u2 = fmaf(wb[r * 3 + 1], vb[r][x + 1], u2); u2 = fmaf(wb[r * 3 + 2], vb[r][x + 2], u2);
         }
         const float g = u1 * u2;
         rsum += g;
@@ -1537,3 +1542,5 @@ inline hipError_t launch_skinny_auto(const GemmP& p, hipStream_t s) {
 }
 
 }  // namespace hd
+
+#pragma clang fp contract(fast)

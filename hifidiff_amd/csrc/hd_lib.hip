@@ -22,6 +22,7 @@
 #include "hd_kernels.hpp"
 #include "hd_tail.hpp"
 #include "hd_vae.hpp"
+#include "hd_xcd.hpp"
 
 using namespace hd;
 
@@ -213,6 +214,15 @@ struct hd_ctx {
     uint4* tail_act = nullptr; float2* tail_stats = nullptr; unsigned *tail_flags = nullptr, *tail_state = nullptr;
     unsigned* tail_tmo_host = nullptr;        // pinned, device-mapped: non-zero after a hand-off wait gave up
     unsigned* tail_tmo_dev = nullptr;
+
+    // XCD-local persistent stages (hd_xcd.hpp): latent 16, batch <= 64, one chain, one FiLM row for all faces
+    struct XStage { XBlockW* blocks_dev = nullptr; unsigned* sync = nullptr; int nblocks = 0; };   // sync: flags | hello | gstate, 256 words each
+    std::map<int, XStage> xstages;            // by index of the stage's first block in den_blocks
+    bool xcd_ok = false;                      // the device and the network allow it (setup_xcd)
+    bool xcd_on = true;                       // run-time switch (hd_set_option "xcd"): off = the per-GEMM launches of the same program
+    int xcd_phase_limit = 0, xcd_force_global = 0;
+    unsigned* xcd_tmo_host = nullptr;         // pinned, device-mapped: non-zero after a hand-off wait gave up
+    unsigned* xcd_tmo_dev = nullptr;
 
     // program
     int op_limit = -1, prep_limit = -1;
@@ -1068,6 +1078,9 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
             const std::string s = std::to_string(l);
             c->dbg["X" + s] = {v.X, {mc, 0}}; c->dbg["Y" + s] = {v.Y, {mc, 0}}; c->dbg["T1_" + s] = {v.T1, {2 * mc, 0}};
             c->dbg["G" + s] = {v.G, {mc, 1}}; c->dbg["pooled" + s] = {v.pooled, {(size_t)B * v.C, 0}}; c->dbg["S" + s] = {v.S, {(size_t)B * v.C, 0}};
+            c->dbg["Xb" + s] = {v.Xb, {mc, 1}}; c->dbg["Yb" + s] = {v.Yb, {mc, 1}}; c->dbg["Xg" + s] = {v.Xg, {mc, 1}};
+            c->dbg["pooled16_" + s] = {v.pooled16, {(size_t)B * v.C, 1}};
+            c->dbg["sx" + s] = {v.sx, {(size_t)v.M * (v.C / 32) * 2, 0}}; c->dbg["sy" + s] = {v.sy, {(size_t)v.M * (v.C / 32) * 2, 0}};
             const std::string ps = std::to_string(pi);
             c->dbg["prior" + ps] = {ch.prior[pi], {mc, 0}}; c->dbg["wc" + ps] = {ch.gate_c[pi], {(size_t)B * v.C, 0}};
             c->dbg["ws" + ps] = {ch.gate_s[pi], {(size_t)v.M, 0}};
@@ -1093,6 +1106,8 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
 
 int build_denoiser_program(hd_ctx* c);
 int setup_mid_tail(hd_ctx* c);
+int get_xstage(hd_ctx* c, int first_block, int nblocks, hd_ctx::XStage** out);
+int setup_xcd(hd_ctx* c);
 
 // Cut the batch into chains (HD_CHAINS, default 1).  Two streams of these kernels do overlap (1.6x in
 // tools/gemm_bench), but halving M does not make a kernel cheaper, so splitting the batch is not a win.
@@ -1158,8 +1173,46 @@ int build_denoiser_program(hd_ctx* c) {
     const int enc[4] = {2, 2, 4, 8};
     int bi = 0;
     int np = 1, cnt = WIDTH;                            // intro emits one (mean, M2) partial per row
+    // A run of blocks of one level: as per-GEMM launches, and -- levels 2 and 3 at latent 16, batch <= 64 -- as ONE
+    // XCD-local persistent launch (hd_xcd.hpp) when its conditions hold at run time (a single chain: every workgroup
+    // must be resident; one FiLM row for all faces).  Both forms compute the same bits.
+    int stage_rc = HD_OK;
+    auto add_stage = [&](int nblk, const Level& lv, const GateOut* gate) {
+        const int first = bi;
+        const bool shape_ok = c->xcd_ok && B <= XS_GROUPS * XS_FACES && np == lv.C / 32 && cnt == 32 &&
+                              ((lv.C == 1024 && lv.H == 2) || (lv.C == 512 && lv.H == 4)) && nblk <= XS_MAXBLK;
+        auto sub = std::make_shared<std::vector<Op>>();
+        for (int j = 0; j < nblk; ++j)
+            add_naf_block(c, shape_ok ? *sub : prog, c->den_blocks[bi++], lv, nullptr, &np, &cnt, (gate && j == nblk - 1) ? gate : nullptr);
+        if (!shape_ok) return;
+        hd_ctx::XStage* xs = nullptr;
+        stage_rc = get_xstage(c, first, nblk, &xs);
+        if (stage_rc) return;
+        XStageP sp{};
+        sp.B = B; sp.nblocks = nblk; sp.blocks = xs->blocks_dev;
+        sp.X = lv.X; sp.Xb = lv.Xb; sp.sx = lv.sx; sp.G = lv.G; sp.Yb = lv.Yb; sp.sy = lv.sy;
+        sp.pooled16 = lv.pooled16; sp.pooled = lv.pooled; sp.S = lv.S; sp.ln_eps = 1e-6f;
+        if (gate) { sp.outg16 = lv.Xg; sp.gate_c = gate->gate_c; sp.gate_s = gate->gate_s; sp.add_src = gate->add; }
+        sp.flags = xs->sync; sp.hello = xs->sync + 256; sp.gstate = xs->sync + 512; sp.tmo = c->xcd_tmo_dev;
+        const bool l3 = lv.C == 1024;
+        Op op;
+        op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
+        op.run = [c, chp, sp, sub, l3](hipStream_t s) -> hipError_t {
+            if (c->xcd_ok && c->xcd_on && c->chains.size() == 1 && c->film_face_stride == 0) {
+                XStageP r = sp;
+                r.film = c->film_from_cur ? chp->film_cur : c->film_table;
+                r.phase_limit = c->xcd_phase_limit; r.force_global = c->xcd_force_global;
+                return l3 ? launch_xcd_stage<1024, 4>(r, s) : launch_xcd_stage<512, 16>(r, s);
+            }
+            for (auto& o : *sub) { const hipError_t e = o.run(s); if (e != hipSuccess) return e; }
+            return hipSuccess;
+        };
+        prog.push_back(op);
+    };
     for (int l = 0; l < 4; ++l) {
-        for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[l], nullptr, &np, &cnt);
+        if (l >= 2) add_stage(enc[l], c->ch->lv[l], nullptr);
+        else for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[l], nullptr, &np, &cnt);
+        if (stage_rc) return stage_rc;
         add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
         np = c->ch->lv[l + 1].C / 32; cnt = 32;
     }
@@ -1205,9 +1258,12 @@ int build_denoiser_program(hd_ctx* c) {
         // LayerNorm partials of the new rows (one per 32 channels)
         add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], cond ? hi.Yb : hi.Xb, true, hi.M, hi.H, hi.C, lo.X, lo.X, 2, lo.Xb, lo.sx);
         np = lo.C / 32; cnt = 32;
-        for (int j = 0; j < 2; ++j) {
-            GateOut g; g.gate_c = c->ch->gate_c[i + 1]; g.gate_s = c->ch->gate_s[i + 1];
-            add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt, (cond && j == 1) ? &g : nullptr);
+        GateOut g; g.gate_c = c->ch->gate_c[i + 1]; g.gate_s = c->ch->gate_s[i + 1];
+        if (l >= 2) {
+            add_stage(2, lo, cond ? &g : nullptr);
+            if (stage_rc) return stage_rc;
+        } else {
+            for (int j = 0; j < 2; ++j) add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt, (cond && j == 1) ? &g : nullptr);
         }
         if (cond) add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
     }
@@ -1738,6 +1794,61 @@ static int check_tail(hd_ctx* c) {
     return HD_OK;
 }
 
+// XCD-local persistent stages (hd_xcd.hpp): usable when every one of the 256 workgroups gets a CU of its own (8 XCDs x 32
+// CUs) and the level geometry is the latent-16 one (4 / 16 pixels per face at levels 3 / 2).  HD_NO_XCD=1 builds the
+// program without them.
+int setup_xcd(hd_ctx* c) {
+    c->xcd_ok = false;
+    if (c->S != 1 || getenv("HD_NO_XCD")) return HD_OK;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || prop.multiProcessorCount != XS_GROUPS * XS_GROUP_WG) return HD_OK;
+    HIPCHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->xcd_tmo_host), 64, hipHostMallocMapped));
+    c->xcd_tmo_host[0] = 0;
+    HIPCHECK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->xcd_tmo_dev), c->xcd_tmo_host, 0));
+    c->xcd_ok = true;
+    return HD_OK;
+}
+// the device-side description of a stage (weights only: shared by every workspace), created on first use
+int get_xstage(hd_ctx* c, int first_block, int nblocks, hd_ctx::XStage** out) {
+    auto it = c->xstages.find(first_block);
+    if (it != c->xstages.end() && it->second.nblocks == nblocks) { *out = &it->second; return HD_OK; }
+    hd_ctx::XStage st;
+    st.nblocks = nblocks;
+    std::vector<XBlockW> host((size_t)nblocks);
+    for (int j = 0; j < nblocks; ++j) {
+        const BlockW& bw = c->den_blocks[first_block + j];
+        XBlockW& x = host[j];
+        x.w1 = bw.conv1.w; x.wsca = bw.sca.w; x.w3 = bw.conv3.w; x.w4 = bw.conv4.w; x.w5 = bw.conv5.w;
+        x.b1 = bw.conv1.bias; x.bsca = bw.sca.bias; x.b3 = bw.conv3.bias; x.b4 = bw.conv4.bias; x.b5 = bw.conv5.bias;
+        x.beta = bw.beta; x.gamma = bw.gamma; x.dw_w = bw.dw_wT; x.dw_b = bw.dw_b; x.film_off = bw.film_off; x.pad_ = 0;
+    }
+    const bool ws = c->ws_scope;
+    c->ws_scope = false;                                  // context-lifetime allocations
+    int rc = dev_alloc(c, &st.blocks_dev, (size_t)nblocks);
+    rc |= dev_alloc(c, &st.sync, (size_t)3 * 256);
+    c->ws_scope = ws;
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpy(st.blocks_dev, host.data(), host.size() * sizeof(XBlockW), hipMemcpyHostToDevice));
+    HIPCHECK(c, hipMemset(st.sync, 0, (size_t)3 * 256 * sizeof(unsigned)));
+    c->xstages[first_block] = st;
+    *out = &c->xstages[first_block];
+    return HD_OK;
+}
+// A hand-off wait of a persistent stage gave up (a workgroup was not resident, or a fault): results since then are
+// garbage.  Reported once; the context then runs one launch per GEMM.
+static int check_xcd(hd_ctx* c) {
+    if (c->xcd_tmo_host && c->xcd_tmo_host[0]) {
+        const unsigned code = c->xcd_tmo_host[0];
+        c->xcd_tmo_host[0] = 0;
+        c->xcd_on = false; c->graphs_valid = false;
+        for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
+        for (auto& kv : c->xstages) (void)hipMemset(kv.second.sync, 0, (size_t)3 * 256 * sizeof(unsigned));
+        HD_FAIL(c, HD_ERR_HIP, "persistent XCD stage: a hand-off wait timed out (code 0x%x); results of the last call are invalid, "
+                               "falling back to one launch per GEMM", code);
+    }
+    return HD_OK;
+}
+
 }  // namespace
 
 // ================================================================================================ C-ABI
@@ -1946,6 +2057,8 @@ int hd_finalize_weights(hd_ctx* c) {
     }
     c->film_total = off;
     rc = setup_mid_tail(c);
+    if (rc) return rc;
+    rc = setup_xcd(c);
     if (rc) return rc;
     off = 0;
     for (int l = 0; l < 4 && c->conditional; ++l)
@@ -2221,6 +2334,8 @@ int hd_eps(hd_ctx* c, const float* x, const float* timesteps, int n_t, float* ep
     if (rc) return rc;
     rc = check_tail(c);
     if (rc) return rc;
+    rc = check_xcd(c);
+    if (rc) return rc;
     if (!x || !timesteps || !eps_out || (n_t != 1 && n_t != c->B)) HD_FAIL(c, HD_ERR_INVALID, "hd_eps: bad arguments (n_t must be 1 or batch)");
     HIPCHECK(c, hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -2248,6 +2363,8 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
     int rc = check_ready(c, true);
     if (rc) return rc;
     rc = check_tail(c);
+    if (rc) return rc;
+    rc = check_xcd(c);
     if (rc) return rc;
     if (!x_inout || !sched || sched->n_steps <= 0 || !sched->timesteps || !sched->coef) HD_FAIL(c, HD_ERR_INVALID, "hd_sample: bad arguments");
     HIPCHECK(c, hipSetDevice(c->device));
@@ -2396,6 +2513,47 @@ int64_t hd_debug_read(hd_ctx* c, const char* name, float* host_out, int64_t max_
     auto it = c->dbg.find(name);
     if (it == c->dbg.end()) HD_FAIL(c, HD_ERR_INVALID, "unknown debug buffer %s", name);
     return read_to_host(c, it->second.first, it->second.second.first, it->second.second.second, host_out, max_elems);
+}
+
+int hd_debug_write(hd_ctx* c, const char* name, const float* host_in, int64_t n_elems) {
+    if (!c || !name || !host_in) return HD_ERR_INVALID;
+    auto it = c->dbg.find(name);
+    if (it == c->dbg.end()) HD_FAIL(c, HD_ERR_INVALID, "unknown debug buffer %s", name);
+    const size_t n = it->second.second.first;
+    if ((int64_t)n != n_elems) HD_FAIL(c, HD_ERR_INVALID, "debug write of %s needs %zu elements", name, n);
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipDeviceSynchronize());
+    if (it->second.second.second) {                        // bf16 buffer: round to nearest even, as the kernels do
+        std::vector<unsigned short> tmp(n);
+        for (size_t i = 0; i < n; ++i) {
+            unsigned u; memcpy(&u, &host_in[i], 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u) { tmp[i] = (unsigned short)((u >> 16) | 0x40u); continue; }   // NaN stays NaN
+            tmp[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        HIPCHECK(c, hipMemcpy(it->second.first, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        HIPCHECK(c, hipMemcpy(it->second.first, host_in, n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return HD_OK;
+}
+
+int hd_set_option(hd_ctx* c, const char* key, int value) {
+    if (!c || !key) return HD_ERR_INVALID;
+    const std::string k = key;
+    if (k == "xcd") c->xcd_on = value != 0;
+    else if (k == "xcd_phase_limit") c->xcd_phase_limit = value;
+    else if (k == "xcd_force_global") c->xcd_force_global = value;
+    else HD_FAIL(c, HD_ERR_INVALID, "unknown option %s", key);
+    c->graphs_valid = false;                               // captured graphs hold the old choice
+    for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
+    return HD_OK;
+}
+int hd_get_option(hd_ctx* c, const char* key) {
+    if (!c || !key) return HD_ERR_INVALID;
+    const std::string k = key;
+    if (k == "xcd") return (c->xcd_ok && c->xcd_on) ? 1 : 0;
+    if (k == "xcd_stages") return (int)c->xstages.size();
+    return HD_ERR_INVALID;
 }
 
 int hd_set_profiling(hd_ctx* c, int on) { if (!c) return HD_ERR_INVALID; c->profiling = on != 0; return HD_OK; }

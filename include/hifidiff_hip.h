@@ -145,6 +145,15 @@ const char* hd_debug_op_name(hd_ctx* ctx, int which, int i);
 int64_t hd_debug_read_op(hd_ctx* ctx, int which, int i, float* host_out, int64_t max_elems);
 /* copy a named internal buffer (DESIGN.md "Buffers") to the host as fp32; returns the element count */
 int64_t hd_debug_read(hd_ctx* ctx, const char* name, float* host_out, int64_t max_elems);
+/* overwrite a named internal buffer from host fp32 (bf16 buffers: rounded to nearest even): tests feed a launch the
+ * oracle's value of its input ("teacher forcing") so that its own error is not buried under inherited drift */
+int hd_debug_write(hd_ctx* ctx, const char* name, const float* host_in, int64_t n_elems);
+/* Run-time switches that select between equivalent launch programs of the same arithmetic (tests compare them bit for
+ * bit; no reference interface corresponds): "xcd" 1/0 = levels 2 / 3 as XCD-local persistent launches (hd_xcd.hpp) or one
+ * launch per GEMM; "xcd_phase_limit" n = stop every persistent stage after n phases (0: all); "xcd_force_global" 1 = its
+ * placement-independent hand-off form.  hd_get_option: "xcd" (effective), "xcd_stages" (stages built so far). */
+int hd_set_option(hd_ctx* ctx, const char* key, int value);
+int hd_get_option(hd_ctx* ctx, const char* key);
 /* HIP-event time in ms of the most recent hd_sample's replay loop (0 if profiling is off) and the
  * summed duration of the GEMM launches: used by bench.py for the roofline object */
 int hd_set_profiling(hd_ctx* ctx, int on);
