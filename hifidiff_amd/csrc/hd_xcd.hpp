@@ -68,7 +68,7 @@ struct XStageP {
     int phase_limit;                      // introspection: stop after this many phases (<= 0: all)
     int force_global;                     // test: use the placement-independent hand-off even when the group shares an XCD
 #ifdef HD_STAMPS
-    unsigned long long* stamps;           // [phase][workgroup][4]
+    unsigned long long* stamps;           // [phase][workgroup][8]: 0 start, 1 barrier passed, 2 K loop done, 3 epilogue stores issued, 4 drained, 5 published
 #endif
 };
 
@@ -103,6 +103,7 @@ struct XLds {
     float pl[XS_FACES * 32];                              // pooled tile / sca tile
     float2 stats[K::RCU];                                 // (mean, rstd) per row
     float gb[2 * C];                                      // FiLM gain | bias
+    float dwc[22 * 32];                                   // per-column constants of the fused depthwise epilogue
     XBlockW blk[XS_MAXBLK];
     unsigned base, local, abort, pad_;
 };
@@ -131,7 +132,7 @@ __device__ __forceinline__ float4 xs_ldg_f4(const float* p) {
 __device__ __forceinline__ void xs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifdef HD_STAMPS
-#define HD_XSTAMP(i) do { if (p.stamps && tid == 0) p.stamps[((size_t)ph * 256 + blockIdx.x) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define HD_XSTAMP(i) do { if (p.stamps && tid == 0) p.stamps[((size_t)ph * 256 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define HD_XSTAMP(i) do { } while (0)
 #endif
@@ -174,19 +175,24 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
     xs_u32x4 aq[K::CPW][4];                                          // raw A units: rows (lane >> 3) + 8u, 8 k at 8 * kq
     f32x16_t acc[2];
 
-    auto load_w = [&](const uint4* W, auto pair_c) {
+    // one 64-deep chunk of this wave's K slice (d = 0, 1).  A wave stalls at ISSUE once the CU's load queue is full (about
+    // 80 KB in flight), so the next phase's weights are requested in two halves with epilogue work in between
+    auto load_w_chunk = [&](const uint4* W, auto pair_c, auto d_c) __attribute__((always_inline)) {
         constexpr bool PAIR = decltype(pair_c)::value;
+        constexpr int d = decltype(d_c)::value;
         const uint4* Wl = W + lane;
 #pragma unroll
-        for (int d = 0; d < K::CPW; ++d)
-#pragma unroll
-            for (int ss = 0; ss < 4; ++ss) {
-                bq[d][ss][0] = xs_ldg_u4(Wl + ((size_t)ct * K::KS + (c0 + d) * 4 + ss) * 64);
-                if (PAIR) bq[d][ss][1] = xs_ldg_u4(Wl + ((size_t)(ct + K::NT) * K::KS + (c0 + d) * 4 + ss) * 64);
-            }
+        for (int ss = 0; ss < 4; ++ss) {
+            bq[d][ss][0] = xs_ldg_u4(Wl + ((size_t)ct * K::KS + (c0 + d) * 4 + ss) * 64);
+            if (PAIR) bq[d][ss][1] = xs_ldg_u4(Wl + ((size_t)(ct + K::NT) * K::KS + (c0 + d) * 4 + ss) * 64);
+        }
+    };
+    auto load_w = [&](const uint4* W, auto pair_c) __attribute__((always_inline)) {
+        load_w_chunk(W, pair_c, std::integral_constant<int, 0>());
+        load_w_chunk(W, pair_c, std::integral_constant<int, 1>());
     };
     // rows of this wave's A sub-tile: tile row (lane >> 3) + 8u of row tile wm
-    auto load_a = [&](const __amdgpu_buffer_rsrc_t& rs) {
+    auto load_a = [&](const __amdgpu_buffer_rsrc_t& rs) __attribute__((always_inline)) {
 #pragma unroll
         for (int d = 0; d < K::CPW; ++d)
 #pragma unroll
@@ -198,14 +204,14 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
     };
     char* sA = L.stage + wave * K::A_WAVE;
     const int a_lane_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
-    auto zero_acc = [&]() {
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
     };
     // one 64-deep chunk: staged units -> LDS (wave-private), four k-steps of MFMA
-    auto chunk_mma = [&](int d, auto pair_c) {
+    auto chunk_mma = [&](int d, auto pair_c) __attribute__((always_inline)) {
         constexpr bool PAIR = decltype(pair_c)::value;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
         __builtin_amdgcn_wave_barrier();
     };
     // K loop on bf16 rows taken as they are (conv3, conv5 inputs)
-    auto gemm_plain = [&](auto pair_c) {
+    auto gemm_plain = [&](auto pair_c) __attribute__((always_inline)) {
         zero_acc();
 #pragma unroll
         for (int d = 0; d < K::CPW; ++d) {
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
     };
     // K loop with LayerNorm2d + FiLM applied to the staged rows (utils.py:16-24, conditional_naf.py:114-115,126-127):
     // the arithmetic of LdF32LN_T<false>::finish_nc
-    auto gemm_ln = [&]() {
+    auto gemm_ln = [&]() __attribute__((always_inline)) {
         zero_acc();
         f32x2_t rsv[4], muv[4];
 #pragma unroll
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
     };
     // K-split partial tiles -> LDS red[wk][tn][row][32] (aliases the staging tiles: barrier first)
     float* red = reinterpret_cast<float*>(L.stage);
-    auto to_red = [&](auto pair_c) {
+    auto to_red = [&](auto pair_c) __attribute__((always_inline)) {
         constexpr int TNT = decltype(pair_c)::value ? 2 : 1;
         constexpr int TILE_F = K::RCU * 32 * TNT;
         xs_lds_barrier();
@@ -280,36 +286,41 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             }
         xs_lds_barrier();
     };
-    // LayerNorm partials of the tile rows -> (mean, rstd) per row in LDS: LdF32LN_T::block_issue / block_finish (fast path)
-    auto ln_stats = [&](const __amdgpu_buffer_rsrc_t& rs, int film_bias_off) {
+    // LayerNorm partials of the tile rows -> (mean, rstd) per row in LDS: LdF32LN_T::block_issue / block_finish (fast path).
+    // The (small) loads go out BEFORE the A rows, the merge runs while those are still arriving (loads return in order).
+    float2 ln_ps[4];
+    float4 ln_g = make_float4(0.f, 0.f, 0.f, 0.f), ln_b = ln_g;
+    auto ln_issue = [&](const __amdgpu_buffer_rsrc_t& rs, int film_bias_off) __attribute__((always_inline)) {
         constexpr int TPR = K::TPR;
         const int rl = tid / TPR, part = tid % TPR, row = row0 + rl;
         const bool rv = row < M;
-        float2 ps[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = part + i * TPR;
-            ps[i] = make_float2(0.f, -1.f);                                   // M2 < 0 marks "no partial"
+            ln_ps[i] = make_float2(0.f, -1.f);                                // M2 < 0 marks "no partial"
             if (rv && j < K::NT) {
                 const xs_u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, (row * K::NT + j) * 8, 0, 16);
-                ps[i] = make_float2(__uint_as_float(raw.x), __uint_as_float(raw.y));
+                ln_ps[i] = make_float2(__uint_as_float(raw.x), __uint_as_float(raw.y));
             }
         }
         // FiLM gain / bias of this LayerNorm: [bias | gain] at film_bias_off (written by an earlier launch: plain loads)
-        {
-            const float* f = p.film;
-#pragma unroll
-            for (int i = 0; i < (C + XS_THREADS * 4 - 1) / (XS_THREADS * 4); ++i) {
-                const int k = (tid + i * XS_THREADS) * 4;
-                if (k < C) {
-                    const float4 bb = *reinterpret_cast<const float4*>(f + film_bias_off + k);
-                    const float4 gg = *reinterpret_cast<const float4*>(f + film_bias_off + C + k);
-                    *reinterpret_cast<float4*>(&L.gb[k]) = gg;
-                    *reinterpret_cast<float4*>(&L.gb[C + k]) = bb;
-                }
-            }
+        static_assert(C <= XS_THREADS * 4, "one float4 of gain and bias per thread");
+        const int k = tid * 4;
+        if (k < C) {
+            ln_b = *reinterpret_cast<const float4*>(p.film + film_bias_off + k);
+            ln_g = *reinterpret_cast<const float4*>(p.film + film_bias_off + C + k);
         }
-        auto row_sum = [](float v) {
+    };
+    auto ln_finish = [&]() __attribute__((always_inline)) {
+        constexpr int TPR = K::TPR;
+        const int rl = tid / TPR, part = tid % TPR;
+        const bool rv = row0 + rl < M;
+        const int k = tid * 4;
+        if (k < C) {
+            *reinterpret_cast<float4*>(&L.gb[k]) = ln_g;
+            *reinterpret_cast<float4*>(&L.gb[C + k]) = ln_b;
+        }
+        auto row_sum = [](float v) __attribute__((always_inline)) {
             if (TPR > 1) v += dpp_mov<0xB1>(v);
             if (TPR > 2) v += dpp_mov<0x4E>(v);
             if (TPR > 4) v += dpp_mov<0x141>(v);
@@ -318,28 +329,30 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
         };
         float sm = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sm += ps[i].y >= 0.f ? ps[i].x : 0.f;
+        for (int i = 0; i < 4; ++i) sm += ln_ps[i].y >= 0.f ? ln_ps[i].x : 0.f;
         const float inv_np = 1.0f / (float)K::NT;
         const float mean = row_sum(sm) * inv_np;
         const float cnt = 32.f;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float d = ps[i].x - mean;
-            q += ps[i].y >= 0.f ? fmaf(cnt * d, d, ps[i].y) : 0.f;
+            const float d = ln_ps[i].x - mean;
+            q += ln_ps[i].y >= 0.f ? fmaf(cnt * d, d, ln_ps[i].y) : 0.f;
         }
         const float var = row_sum(q) * (inv_np / cnt);
         if (part == 0) L.stats[rl] = make_float2(mean, rv ? __frsqrt_rn(var + p.ln_eps) : 0.f);
         xs_lds_barrier();
     };
-    // hand-off stores: plain inside one XCD, write-through otherwise (wave-uniform)
+    // hand-off stores: plain inside one XCD, write-through otherwise (wave-uniform).  ONLY WAVE 0 stores hand-off data: the other
+    // waves request the next phase's weights as soon as their K loop has consumed the current ones, and a wave with loads in
+    // flight cannot drain its stores without waiting for those loads too (one in-order counter).
     bool local = false;
-    auto st128 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, uint4 v) {
+    auto st128 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, uint4 v) __attribute__((always_inline)) {
         const xs_u32x4 x = {v.x, v.y, v.z, v.w};
         if (local) __builtin_amdgcn_raw_buffer_store_b128(x, rs, off, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b128(x, rs, off, 0, 16);
     };
-    auto st64 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float2 v) {
+    auto st64 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float2 v) __attribute__((always_inline)) {
         const xs_u32x2 x = {__float_as_uint(v.x), __float_as_uint(v.y)};
         if (local) __builtin_amdgcn_raw_buffer_store_b64(x, rs, off, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b64(x, rs, off, 0, 16);
@@ -347,20 +360,16 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
     xs_gu32* flags = (xs_gu32*)(p.flags + group * 32);
     unsigned base = 0;
     bool dead = false;
-    // end of a phase: every storing wave drains its stores (arrive), the next phase's weights are requested (after the
-    // drain, so that it does not wait for them), the workgroup's barrier, then one lane stores the flag (publish)
-    auto arrive = [&](int) {
+    // end of a phase (wave 0, after the barrier behind the epilogue): its stores are drained, then one lane stores the flag
+    auto publish = [&](int ph) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    auto publish = [&](int ph) {
-        xs_lds_barrier();
-        if (tid == 0) {
+        if (lane == 0) {
             if (local) __hip_atomic_store(flags + rank, base + (unsigned)ph + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(flags + rank, base + (unsigned)ph + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    // wait until all 32 workgroups of the group have published phase ph
-    auto wait_phase = [&](int ph) {
+    // wait until all 32 workgroups of the group have published phase ph (wave 0 polls: it has no load in flight)
+    auto wait_phase = [&](int ph) __attribute__((always_inline)) {
         if (wave == 0) {
             const unsigned want = base + (unsigned)ph + 1u;
             for (unsigned spins = 0;; ++spins) {
@@ -376,6 +385,8 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
         xs_lds_barrier();
         dead = L.abort != 0u;
     };
+    // the tile row -> LayerNorm partial (mean, M2) of its 32 columns, kept in LDS for wave 0's store pass
+    float2* st_out = L.stats;                                        // (mean, rstd) of the rows are dead once the K loop is over
 
     // ---- weights of the first phase, then the start-of-launch handshake ----
     load_w(L.blk[0].w1, std::true_type());
@@ -419,19 +430,34 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             const int ph = 5 * blk;
             if (ph >= P_run) break;
             HD_XSTAMP(0);
-            if (ph > 0) { wait_phase(ph - 1); if (dead) return; }
+            if (ph > 0) { wait_phase(ph - 1); if (dead) return; if (wave == 0) load_w(B.w1, std::true_type()); }
             HD_XSTAMP(1);
+            ln_issue(rs_sx, B.film_off);
             load_a(rs_Xb);
-            // per-channel constants of the fused epilogue (weights: plain loads)
-            float dw_wa[9], dw_wb[9];
+            // per-channel constants of the fused epilogue (weights: plain loads), parked in LDS until the epilogue: 22 values per
+            // column (9 + 9 depthwise taps of the two gate halves, their biases, conv1's biases); two loads per thread
+            float dwc[2];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) { dw_wa[t] = xs_ldg_f(B.dw_w + (size_t)t * 2 * C + col); dw_wb[t] = xs_ldg_f(B.dw_w + (size_t)t * 2 * C + col + C); }
-            const float dw_ba = xs_ldg_f(B.dw_b + col), dw_bb = xs_ldg_f(B.dw_b + col + C), b1a = xs_ldg_f(B.b1 + col), b1b = xs_ldg_f(B.b1 + col + C);
-            ln_stats(rs_sx, B.film_off);
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * XS_THREADS, k = e >> 5, cc = ct * 32 + (e & 31);
+                dwc[i] = 0.f;
+                if (k < 18) dwc[i] = xs_ldg_f(B.dw_w + (size_t)(k % 9) * 2 * C + cc + (k >= 9 ? C : 0));
+                else if (k < 20) dwc[i] = xs_ldg_f(B.dw_b + cc + (k == 19 ? C : 0));
+                else if (k < 22) dwc[i] = xs_ldg_f(B.b1 + cc + (k == 21 ? C : 0));
+            }
+            ln_finish();
             gemm_ln();
+            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.wsca, std::false_type(), std::integral_constant<int, 0>());
             HD_XSTAMP(2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { const int e = tid + i * XS_THREADS; if (e < 22 * 32) L.dwc[e] = dwc[i]; }
             to_red(std::true_type());
             constexpr int TILE_F = K::RCU * 32 * 2;
+            float dw_wa[9], dw_wb[9];
+            const int jc = tid & 31;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { dw_wa[t] = L.dwc[t * 32 + jc]; dw_wb[t] = L.dwc[(9 + t) * 32 + jc]; }
+            const float dw_ba = L.dwc[18 * 32 + jc], dw_bb = L.dwc[19 * 32 + jc], b1a = L.dwc[20 * 32 + jc], b1b = L.dwc[21 * 32 + jc];
             // (1) sum the K-split partials in wave order, add conv1's bias, keep T1 in slice 0
             for (int e = tid; e < K::RCU * 32; e += XS_THREADS) {
                 float va = b1a, vb = b1b;
@@ -460,20 +486,23 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 L.pl[f * 32 + j] = sacc / (float)HW;
             }
             xs_lds_barrier();
-            if (tid < K::FCU * 4) {
-                const int f = tid >> 2, q4 = tid & 3;
-                if (face0 + f < p.B) {
-                    st128(rs_P16, ((face0 + f) * C + ct * 32 + q4 * 8) * 2, pack8(&L.pl[f * 32 + q4 * 8]));
-                    if (p.pooled) {
-                        *reinterpret_cast<float4*>(p.pooled + (size_t)(face0 + f) * C + ct * 32 + q4 * 8) = *reinterpret_cast<const float4*>(&L.pl[f * 32 + q4 * 8]);
-                        *reinterpret_cast<float4*>(p.pooled + (size_t)(face0 + f) * C + ct * 32 + q4 * 8 + 4) = *reinterpret_cast<const float4*>(&L.pl[f * 32 + q4 * 8 + 4]);
+            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.wsca, std::false_type(), std::integral_constant<int, 1>());
+            HD_XSTAMP(3);
+            if (wave == 0) {
+                if (lane < K::FCU * 4) {
+                    const int f = lane >> 2, q4 = lane & 3;
+                    if (face0 + f < p.B) {
+                        st128(rs_P16, ((face0 + f) * C + ct * 32 + q4 * 8) * 2, pack8(&L.pl[f * 32 + q4 * 8]));
+                        if (p.pooled) {
+                            *reinterpret_cast<float4*>(p.pooled + (size_t)(face0 + f) * C + ct * 32 + q4 * 8) = *reinterpret_cast<const float4*>(&L.pl[f * 32 + q4 * 8]);
+                            *reinterpret_cast<float4*>(p.pooled + (size_t)(face0 + f) * C + ct * 32 + q4 * 8 + 4) = *reinterpret_cast<const float4*>(&L.pl[f * 32 + q4 * 8 + 4]);
+                        }
                     }
                 }
+                HD_XSTAMP(4);
+                publish(ph);
             }
-            arrive(ph);
-            load_w(B.wsca, std::false_type());
-            publish(ph);
-            HD_XSTAMP(3);
+            HD_XSTAMP(5);
         }
         // ======================= q1: s = sca(pooled) ; G <- bf16(G * s) =======================
         {
@@ -481,6 +510,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             if (ph >= P_run) break;
             HD_XSTAMP(0);
             wait_phase(ph - 1); if (dead) return;
+            if (wave == 0) load_w(B.wsca, std::false_type());
             HD_XSTAMP(1);
             const float bsca = xs_ldg_f(B.bsca + col);
             zero_acc();
@@ -499,6 +529,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                     chunk_mma(d, std::false_type());
                 }
             }
+            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w3, std::false_type(), std::integral_constant<int, 0>());
             HD_XSTAMP(2);
             // partial tiles of the 8 face rows -> LDS, summed in wave order
             xs_lds_barrier();
@@ -515,26 +546,29 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
 #pragma unroll
                 for (int w = 0; w < K::WK; ++w) v += red[w * (XS_FACES * 32) + tid];
                 L.pl[tid] = v;
-                if (p.S && face0 + (tid >> 5) < p.B) p.S[(size_t)(face0 + (tid >> 5)) * C + col] = v;
             }
             xs_lds_barrier();
-            // G' = bf16(bf16(g) * s[face]) for this workgroup's tile: 16-byte units (row, 8 columns)
-            if (tid < K::RCU * 4) {
-                const int r = tid >> 2, q4 = tid & 3;
-                if (row0 + r < M) {
-                    const uint4 g = *reinterpret_cast<const uint4*>(&L.gt[r * 32 + q4 * 8]);
-                    float v[8];
-                    unpack8(g, v);
-                    const float* sp = &L.pl[(r / HW) * 32 + q4 * 8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] *= sp[i];
-                    st128(rs_G, ((row0 + r) * C + ct * 32 + q4 * 8) * 2, pack8(v));
-                }
-            }
-            arrive(ph);
-            load_w(B.w3, std::false_type());
-            publish(ph);
+            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w3, std::false_type(), std::integral_constant<int, 1>());
             HD_XSTAMP(3);
+            if (wave == 0) {
+                // G' = bf16(bf16(g) * s[face]) for this workgroup's tile: 16-byte units (row, 8 columns)
+                for (int u = lane; u < K::RCU * 4; u += 64) {
+                    const int r = u >> 2, q4 = u & 3;
+                    if (row0 + r < M) {
+                        const uint4 g = *reinterpret_cast<const uint4*>(&L.gt[r * 32 + q4 * 8]);
+                        float v[8];
+                        unpack8(g, v);
+                        const float* sp = &L.pl[(r / HW) * 32 + q4 * 8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] *= sp[i];
+                        st128(rs_G, ((row0 + r) * C + ct * 32 + q4 * 8) * 2, pack8(v));
+                    }
+                }
+                if (p.S) for (int e = lane; e < K::FCU * 32; e += 64) if (face0 + (e >> 5) < p.B) p.S[(size_t)(face0 + (e >> 5)) * C + ct * 32 + (e & 31)] = L.pl[e];
+                HD_XSTAMP(4);
+                publish(ph);
+            }
+            HD_XSTAMP(5);
         }
         // ======================= q2: conv3 ; y = x + beta * (.) ; LayerNorm partials =======================
         {
@@ -542,10 +576,12 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             if (ph >= P_run) break;
             HD_XSTAMP(0);
             wait_phase(ph - 1); if (dead) return;
+            if (wave == 0) load_w(B.w3, std::false_type());
             HD_XSTAMP(1);
             load_a(rs_G);
             const float b3 = xs_ldg_f(B.b3 + col), beta = xs_ldg_f(B.beta + col);
             gemm_plain(std::false_type());
+            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w4, std::true_type(), std::integral_constant<int, 0>());
             HD_XSTAMP(2);
             to_red(std::false_type());
             constexpr int TILE_F = K::RCU * 32;
@@ -566,21 +602,22 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 for (int it = 0; it < K::NIT; ++it) ms[it] = halfwave_mean_m2(v[it]);
                 if ((tid & 31) == kStatLane) {
 #pragma unroll
-                    for (int it = 0; it < K::NIT; ++it) {
-                        const int row = row0 + ((it * XS_THREADS + tid) >> 5);
-                        if (row < M) st64(rs_sy, (row * K::NT + ct) * 8, ms[it]);
-                    }
+                    for (int it = 0; it < K::NIT; ++it) st_out[(it * XS_THREADS + tid) >> 5] = ms[it];
                 }
             }
             xs_lds_barrier();
-            if (tid < K::RCU * 4) {
-                const int r = tid >> 2, q4 = tid & 3;
-                if (row0 + r < M) st128(rs_Yb, ((row0 + r) * C + ct * 32 + q4 * 8) * 2, pack8(&L.yt[r * 32 + q4 * 8]));
-            }
-            arrive(ph);
-            load_w(B.w4, std::true_type());
-            publish(ph);
+            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w4, std::true_type(), std::integral_constant<int, 1>());
             HD_XSTAMP(3);
+            if (wave == 0) {
+                for (int u = lane; u < K::RCU * 4; u += 64) {
+                    const int r = u >> 2, q4 = u & 3;
+                    if (row0 + r < M) st128(rs_Yb, ((row0 + r) * C + ct * 32 + q4 * 8) * 2, pack8(&L.yt[r * 32 + q4 * 8]));
+                }
+                for (int r = lane; r < K::RCU; r += 64) if (row0 + r < M) st64(rs_sy, ((row0 + r) * K::NT + ct) * 8, st_out[r]);
+                HD_XSTAMP(4);
+                publish(ph);
+            }
+            HD_XSTAMP(5);
         }
         // ======================= q3: LN + FiLM -> conv4 -> SimpleGate =======================
         {
@@ -588,11 +625,14 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             if (ph >= P_run) break;
             HD_XSTAMP(0);
             wait_phase(ph - 1); if (dead) return;
+            if (wave == 0) load_w(B.w4, std::true_type());
             HD_XSTAMP(1);
+            ln_issue(rs_sy, B.film_off + 2 * C);
             load_a(rs_Yb);
             const float b4a = xs_ldg_f(B.b4 + col), b4b = xs_ldg_f(B.b4 + col + C);
-            ln_stats(rs_sy, B.film_off + 2 * C);
+            ln_finish();
             gemm_ln();
+            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w5, std::false_type(), std::integral_constant<int, 0>());
             HD_XSTAMP(2);
             to_red(std::true_type());
             constexpr int TILE_F = K::RCU * 32 * 2;
@@ -605,14 +645,17 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 L.gt[e] = f32_to_bf16_bits((v1 + b4a) * (v2 + b4b));
             }
             xs_lds_barrier();
-            if (tid < K::RCU * 4) {
-                const int r = tid >> 2, q4 = tid & 3;
-                if (row0 + r < M) st128(rs_G, ((row0 + r) * C + ct * 32 + q4 * 8) * 2, *reinterpret_cast<const uint4*>(&L.gt[r * 32 + q4 * 8]));
-            }
-            arrive(ph);
-            load_w(B.w5, std::false_type());
-            publish(ph);
+            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w5, std::false_type(), std::integral_constant<int, 1>());
             HD_XSTAMP(3);
+            if (wave == 0) {
+                for (int u = lane; u < K::RCU * 4; u += 64) {
+                    const int r = u >> 2, q4 = u & 3;
+                    if (row0 + r < M) st128(rs_G, ((row0 + r) * C + ct * 32 + q4 * 8) * 2, *reinterpret_cast<const uint4*>(&L.gt[r * 32 + q4 * 8]));
+                }
+                HD_XSTAMP(4);
+                publish(ph);
+            }
+            HD_XSTAMP(5);
         }
         // ======================= q4: conv5 ; x' = y + gamma * (.) ; LayerNorm partials =======================
         {
@@ -620,12 +663,14 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             if (ph >= P_run) break;
             HD_XSTAMP(0);
             wait_phase(ph - 1); if (dead) return;
+            if (wave == 0) load_w(B.w5, std::false_type());
             HD_XSTAMP(1);
             load_a(rs_G);
             const float b5 = xs_ldg_f(B.b5 + col), gamma = xs_ldg_f(B.gamma + col);
             const bool last = (ph == P_run - 1);
             const bool gated = last && ph == P - 1 && p.outg16 != nullptr;
             gemm_plain(std::false_type());
+            if (wave != 0 && !last) load_w_chunk(L.blk[blk + 1].w1, std::true_type(), std::integral_constant<int, 0>());
             HD_XSTAMP(2);
             to_red(std::false_type());
             constexpr int TILE_F = K::RCU * 32;
@@ -646,20 +691,25 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 for (int it = 0; it < K::NIT; ++it) ms[it] = halfwave_mean_m2(v[it]);
                 if ((tid & 31) == kStatLane) {
 #pragma unroll
-                    for (int it = 0; it < K::NIT; ++it) {
-                        const int row = row0 + ((it * XS_THREADS + tid) >> 5);
-                        if (row < M) st64(rs_sx, (row * K::NT + ct) * 8, ms[it]);
-                    }
+                    for (int it = 0; it < K::NIT; ++it) st_out[(it * XS_THREADS + tid) >> 5] = ms[it];
                 }
             }
             xs_lds_barrier();
-            if (tid < K::RCU * 4) {
-                const int r = tid >> 2, q4 = tid & 3;
-                const int row = row0 + r;
-                if (row < M) {
-                    const float* xv = &L.xt[r * 32 + q4 * 8];
-                    if (!gated) st128(rs_Xb, (row * C + ct * 32 + q4 * 8) * 2, pack8(xv));
-                    if (last) {                                           // exit: what the following launches read
+            if (wave != 0 && !last) load_w_chunk(L.blk[blk + 1].w1, std::true_type(), std::integral_constant<int, 1>());
+            HD_XSTAMP(3);
+            if (wave == 0 && !gated) {
+                for (int u = lane; u < K::RCU * 4; u += 64) {
+                    const int r = u >> 2, q4 = u & 3;
+                    if (row0 + r < M) st128(rs_Xb, ((row0 + r) * C + ct * 32 + q4 * 8) * 2, pack8(&L.xt[r * 32 + q4 * 8]));
+                }
+                for (int r = lane; r < K::RCU; r += 64) if (row0 + r < M) st64(rs_sx, ((row0 + r) * K::NT + ct) * 8, st_out[r]);
+            }
+            if (last) {                                                   // exit: what the following launches read (kernel boundary)
+                if (tid < K::RCU * 4) {
+                    const int r = tid >> 2, q4 = tid & 3;
+                    const int row = row0 + r;
+                    if (row < M) {
+                        const float* xv = &L.xt[r * 32 + q4 * 8];
                         float* xo = p.X + (size_t)row * C + ct * 32 + q4 * 8;
                         *reinterpret_cast<float4*>(xo) = *reinterpret_cast<const float4*>(xv);
                         *reinterpret_cast<float4*>(xo + 4) = *reinterpret_cast<const float4*>(xv + 4);
@@ -678,13 +728,11 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                         }
                     }
                 }
-            }
-            if (!last) {
-                arrive(ph);
-                load_w(L.blk[blk + 1].w1, std::true_type());
+            } else if (wave == 0) {
+                HD_XSTAMP(4);
                 publish(ph);
             }
-            HD_XSTAMP(3);
+            HD_XSTAMP(5);
         }
     }
     // the group's launch counter: every member has read it (the handshake completed before rank 0 got here)

@@ -179,6 +179,46 @@ def gen_ddpm_slices(args):
 
 
 @torch.no_grad()
+def gen_full_trajectories(args, which):
+    """The full loops of BASELINE configs[1] / configs[3] in miniature, reference network inside the restated schedulers:
+      ddpm1000: FacialRefiner(16), B = 2, all 1000 DDPM steps (clip 3.0, fixed_small variance, committed-seed noise
+                synth.ddpm_noise(step, face, 16)); the latent after every 100 steps and the final one;
+      ddim250:  FacialRefiner(32), B = 1, all 250 DDIM steps (eta 0, clip 3.0); the latent after every 50 steps and the final one.
+    The conditioning (fpg, idc) is evaluated once and passed to `net.denoiser(...)` (models/refiner.py:33-38 computes the same
+    tensors again in every step: identical values, 2.5x the CPU time)."""
+    FacialRefiner = import_reference(args.ref)[0]
+    L, B, kind, n, every = (16, 2, "ddpm", 1000, 100) if which == "ddpm1000" else (32, 1, "ddim", 250, 50)
+    net = FacialRefiner(L).eval()
+    net.load_state_dict(synth.refiner_state_dict(L), strict=True)
+    x, crl, crf = synth.sample_inputs(B, L)
+    pri, emb = net.fpg(crl), net.idc(crf)
+    if kind == "ddpm":
+        sch = O.DDPMScheduler(clip_sample=True, clip_sample_range=3.0)
+    else:
+        sch = O.DDIMScheduler(clip_sample=True, clip_sample_range=3.0)
+        sch.set_timesteps(n)
+    ts = list(sch.timesteps)
+    assert len(ts) == n
+    lat = x.clone()
+    out = {}
+    t0 = time.time()
+    for i, t in enumerate(ts):
+        eps = net.denoiser(lat, torch.full((B,), int(t)), pri, emb).sample
+        if kind == "ddpm":
+            z = T(np.stack([synth.ddpm_noise(i, b, L) for b in range(B)]))
+            lat = sch.step(eps, int(t), lat, noise=z).prev_sample
+        else:
+            lat = sch.step(eps, int(t), lat).prev_sample
+        if (i + 1) % every == 0:
+            out[f"step{i + 1}"] = lat.numpy().copy()
+            print(which, i + 1, f"{time.time() - t0:.0f}s", float(lat.abs().max()), float(lat.std()), flush=True)
+    out["final"] = lat.numpy()
+    name = "ddpm1000_L16.npz" if which == "ddpm1000" else "ddim250_L32.npz"
+    np.savez_compressed(os.path.join(args.out, name), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+@torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -198,6 +238,8 @@ def main():
         return gen_cr_wild(args)
     if args.only == "ddpmslices":
         return gen_ddpm_slices(args)
+    if args.only in ("ddpm1000", "ddim250"):
+        return gen_full_trajectories(args, args.only)
     FacialRefiner, CondBlock, PosEmb, HCA = import_reference(args.ref)
 
     t0 = time.time()

@@ -54,9 +54,20 @@ def test_library_is_the_one_in_tree(gpu):
     assert _lib.lib().hd_create is not None
 
 
-def test_op_by_op_against_oracle(gpu, weights16, model2, inputs2):
+@pytest.fixture(scope="module")
+def model2_launches(gpu, weights16):
+    """The program with one launch per GEMM at every level (HD_NO_XCD=1 at creation): 151 launches, every one with a tap."""
+    os.environ["HD_NO_XCD"] = "1"
+    try:
+        return make_model(weights16)
+    finally:
+        del os.environ["HD_NO_XCD"]
+
+
+def test_op_by_op_against_oracle(gpu, weights16, model2_launches, inputs2):
     """Every launch of the prologue and of one denoiser evaluation vs the oracle tap of the same name."""
     import op_parity
+    model2 = model2_launches
     x, crl, crf = inputs2
     # Bound per launch: 1.5 x the emulation's own noise floor at that tap + 2.5e-3.  The floor is the bf16-operand oracle
     # against itself on inputs perturbed by 2e-7: rounding decisions decorrelate once two evaluations differ by a fraction
@@ -646,3 +657,53 @@ def test_vae_boundary_against_oracle(gpu):
     with pytest.raises(RuntimeError):
         vae.encode(x[:, :2].cuda())                                                      # wrong channel count
     assert tuple(vae.decode_scaled(z[:0].cuda()).shape) == (0, 3, 128, 128)
+
+
+def _opt(m, key, v):
+    from hifidiff_amd import _lib
+    _lib.check(_lib.lib().hd_set_option(m.engine.ctx, key.encode(), int(v)), m.engine.ctx)
+
+
+def test_xcd_stages_match_the_per_gemm_launches_bit_for_bit(gpu, weights16):
+    """Levels 2 and 3 as XCD-local persistent launches (hd_xcd.hpp: 8 faces per XCD, flag-line barrier in the XCD's L2) against
+    the per-GEMM launches of the same blocks (hd_set_option "xcd" 0): the same arithmetic in the same order, so the SAME BITS --
+    eps at the benchmark batch and at ragged batches, the placement-independent hand-off form, 30 graph-replayed DDPM steps.
+    Parity of the per-GEMM launches against the oracle / the reference goldens is what the other tests establish."""
+    from hifidiff_amd import _lib, sampling, schedulers, synth
+    L = _lib.lib()
+    m = make_model(weights16)
+    for B in (64, 13, 5):
+        x, crl, crf = [t.cuda() for t in synth.sample_inputs(B, 16)]
+        _opt(m, "xcd", 1)
+        e1 = m(x, 500, crf, crl).sample.clone()
+        assert L.hd_get_option(m.engine.ctx, b"xcd") == 1 and L.hd_get_option(m.engine.ctx, b"xcd_stages") == 4
+        assert L.hd_num_ops(m.engine.ctx, 0) == 75                     # 151 launches with one per GEMM: 80 became 4
+        assert torch.equal(m(x, 500, crf, crl).sample, e1)              # reproducible
+        _opt(m, "xcd_force_global", 1)
+        eg = m(x, 500, crf, crl).sample.clone()
+        _opt(m, "xcd_force_global", 0)
+        _opt(m, "xcd", 0)
+        e0 = m(x, 500, crf, crl).sample.clone()
+        assert bool(torch.isfinite(e0).all())
+        assert torch.equal(e1, e0), (B, rel_l2(e1.cpu(), e0.cpu()))
+        assert torch.equal(eg, e0), B
+        tf = (torch.arange(B, device="cuda") * 7 % 1000).float()        # per-face FiLM rows: the stages step aside
+        _opt(m, "xcd", 1)
+        ef1 = m(x, tf, crf, crl).sample.clone()
+        _opt(m, "xcd", 0)
+        assert torch.equal(ef1, m(x, tf, crf, crl).sample)
+    sch = schedulers.DDPMScheduler(clip_sample_range=3.0)
+    sch.timesteps = sch.timesteps[:30]
+    _opt(m, "xcd", 1)
+    a = sampling.sample(m, x, crf, crl, sch, seed=3)
+    b = sampling.sample(m, x, crf, crl, sch, seed=3)
+    _opt(m, "xcd", 0)
+    c = sampling.sample(m, x, crf, crl, sch, seed=3)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    # batch 2: the per-GEMM launches use 16-row tiles there (another LayerNorm merge tree): equal to accumulation order only
+    x, crl, crf = [t.cuda() for t in synth.sample_inputs(2, 16)]
+    _opt(m, "xcd", 1)
+    e1 = m(x, 500, crf, crl).sample.clone()
+    _opt(m, "xcd", 0)
+    assert rel_l2(e1.cpu(), m(x, 500, crf, crl).sample.cpu()) <= 4e-3
+    _opt(m, "xcd", 1)
