@@ -48,26 +48,77 @@ def _requested_gpus(argv):
 def self_launch(n):
     """Parent of a plain `python bench.py --gpus N` (N > 1): N child processes, one rank each.  Nothing here
     touches the GPU (torch is not even imported yet): a process that has initialised HIP must never be the
-    one that starts or re-execs workers."""
+    one that starts or re-execs workers.  All children are polled: when one exits non-zero the others (fresh
+    child processes of this parent) are terminated, the failing rank and the tail of its stderr are printed
+    and the parent returns non-zero within seconds -- rank 0 is never left waiting in the rendezvous."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="hd_bench_ranks_")
+    procs, errs, outs = [], [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HD_BENCH_SELF_LAUNCHED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
-    codes = [p.wait() for p in procs]
-    if out0:
-        sys.stdout.write(out0.decode())
+        errs.append(open(os.path.join(logdir, "rank%d.stderr" % r), "w+"))
+        outs.append(open(os.path.join(logdir, "rank%d.stdout" % r), "w+"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=outs[r], stderr=errs[r]))
+    limit = float(os.environ.get("HD_BENCH_RANK_TIMEOUT", "3000"))            # s: a hung job ends with diagnostics, not silently
+    t0 = time.time()
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None or time.time() - t0 > limit:
+            break
+        time.sleep(0.2)
+    timed_out = failed is None and any(c is None for c in codes)
+    if failed is not None or timed_out:
+        grace = time.time() + 3.0                                               # ranks that are failing for the same reason finish by themselves
+        while failed is not None and time.time() < grace and any(c is None for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = pr.poll()
+            time.sleep(0.1)
+        for r, pr in enumerate(procs):                                          # the remaining ranks wait for the dead one: end them
+            if codes[r] is None:
+                pr.terminate()
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                try:
+                    codes[r] = pr.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    codes[r] = pr.wait()
+
+    def tail(f, nbytes=3000):
+        f.flush(); f.seek(0, 2)
+        size = f.tell()
+        f.seek(max(0, size - nbytes))
+        return f.read()
+    for r in range(n):                                                          # every rank's stderr reaches the caller
+        t = tail(errs[r])
+        if t.strip():
+            sys.stderr.write("---- bench.py rank %d stderr (tail) ----\n%s\n" % (r, t.rstrip()))
+    out0 = tail(outs[0], 1 << 20)
+    if out0 and failed is None and not timed_out:
+        sys.stdout.write(out0)
         sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+    for f in errs + outs:
+        f.close()
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %s first; ranks failed (rank, exit code): %s; per-rank logs in %s\n"
+                         % (failed, codes[failed], [(r, c) for r, c in enumerate(codes) if c != 0], logdir))
+        return 1
+    if timed_out:
+        sys.stderr.write("bench.py: ranks still running after %.0f s were terminated (rank, exit code): %s; per-rank logs in %s\n"
+                         % (limit, list(enumerate(codes)), logdir))
         return 1
     return 0
 
@@ -170,6 +221,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HD_BENCH_TEST_FAIL_RANK") == str(rank):                 # tests: this rank dies before the rendezvous
+        sys.stderr.write("bench.py rank %d/%d: exiting early (HD_BENCH_TEST_FAIL_RANK)\n" % (rank, world))
+        raise SystemExit(7)
     if world != a.gpus:
         raise SystemExit("bench.py rank %d/%d: --gpus %d does not match WORLD_SIZE %d" % (rank, world, a.gpus, world))
     torch.set_grad_enabled(False)
@@ -185,7 +239,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("HD_BENCH_PG_TIMEOUT", "300"))))
 
     from hifidiff_amd import _lib, distributed, sampling, schedulers, synth
     from hifidiff_amd.refiner import FacialRefiner

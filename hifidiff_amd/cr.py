@@ -38,9 +38,8 @@ class CoarseRestoration(nn.Module):
                 raise RuntimeError("size mismatch for %s: got %s, expected %s" % (k, tuple(state_dict[k].shape), tuple(shape)))
         base = self._state or {}
         self._state = {k: (state_dict[k] if k in state_dict else base[k]).detach() for k in man if (k in state_dict or k in base)}
-        self._loaded = False
         if self._ctx is not None:
-            self._upload()
+            self._upload()                                 # a context whose weights are finalized is replaced (self._loaded)
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def state_dict(self, *a, **k):

@@ -74,8 +74,25 @@ class AutoencoderKL(nn.Module):
         return m
 
     # ---- state dict plumbing ----
+    # diffusers < 0.17 checkpoints (the SD-2.x era VAE files among them) name the mid-block attention projections
+    # query / key / value / proj_attn; diffusers 0.32.2 renames them at load time (_convert_deprecated_attention_blocks)
+    _DEPRECATED_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+    @classmethod
+    def _canonical_keys(cls, sd, man):
+        out = {}
+        for k, v in sd.items():
+            parts = k.split(".")
+            if len(parts) >= 3 and parts[-2] in cls._DEPRECATED_ATTN and "attentions" in parts:
+                k = ".".join(parts[:-2] + [cls._DEPRECATED_ATTN[parts[-2]], parts[-1]])
+            if k not in man and not torch.is_tensor(v):
+                continue                                   # non-weight entries (metadata some exporters add)
+            out[k] = v
+        return out
+
     def load_state_dict(self, sd, strict=True):
         man = arch.vae_manifest()
+        sd = self._canonical_keys(sd, man)
         missing = [k for k in man if k not in sd]
         unexpected = [k for k in sd if k not in man]
         if strict and (missing or unexpected):
@@ -87,9 +104,8 @@ class AutoencoderKL(nn.Module):
                 if got != tuple(shape) and not (len(shape) == 2 and got == tuple(shape) + (1, 1)):   # older checkpoints store the attention Linear as 1x1 conv
                     raise RuntimeError("size mismatch for %s: got %s, expected %s" % (k, got, tuple(shape)))
         self._state = {k: sd[k].detach().reshape(man[k][0]) for k in man if k in sd}
-        self._loaded = False
         if self._ctx is not None:
-            self._upload()
+            self._upload()                                 # a context whose weights are finalized is replaced (self._loaded)
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def state_dict(self, *a, **k):

@@ -707,3 +707,50 @@ def test_xcd_stages_match_the_per_gemm_launches_bit_for_bit(gpu, weights16):
     _opt(m, "xcd", 0)
     assert rel_l2(e1.cpu(), m(x, 500, crf, crl).sample.cpu()) <= 4e-3
     _opt(m, "xcd", 1)
+
+
+def test_parked_graphs_follow_a_moved_coefficient_buffer(gpu, weights16):
+    """A longer schedule re-allocates the scheduler-coefficient buffer; workspaces parked for other batch sizes captured the old
+    address into their step graphs (ending launch) and must re-capture too.  Sequence from the r02 review: per-face forward
+    (FiLM rows >= steps, so the FiLM table does not move and cannot mask the bug), B = 4 and B = 3 with a short schedule, B = 3
+    with a longer one, then B = 4 with the longer one."""
+    from hifidiff_amd import sampling, schedulers, synth
+    xs, crls, crfs = [t.cuda() for t in synth.sample_inputs(8, 16)]
+    m = make_model(weights16)
+    m(xs, torch.arange(8, device="cuda") * 100.0, crfs, crls)          # 8 FiLM rows
+
+    def run(model, B, n):
+        sch = schedulers.DDIMScheduler(clip_sample_range=3.0)
+        sch.set_timesteps(50)
+        sch.timesteps = sch.timesteps[:n]
+        return sampling.sample(model, xs[:B], crfs[:B], crls[:B], sch)
+    run(m, 4, 5); run(m, 3, 5); run(m, 3, 7)
+    got = run(m, 4, 7)
+    fresh = make_model(weights16)
+    fresh(xs, torch.arange(8, device="cuda") * 100.0, crfs, crls)
+    assert torch.equal(got, run(fresh, 4, 7))
+
+
+def test_submodule_calls_do_not_leave_a_stale_conditioning_cache(gpu, weights16):
+    """`model.fpg(x)` / `model.idc(x)` with another batch size than the prepared one switch the library's workspace: the next
+    forward() with the SAME (cached) conditioning tensors must prepare again instead of failing; FusedDenoiser.forward caches the
+    gates on prior identity; load_state_dict on a live model replaces the packed weights."""
+    from hifidiff_amd import synth
+    m = make_model(weights16)
+    x, crl, crf = [t.cuda() for t in synth.sample_inputs(3, 16)]
+    e0 = m(x, 500, crf, crl).sample.clone()
+    m.fpg(crl[:1]); m.idc(crf[:2])                                      # batches 1 and 2: other workspaces
+    assert torch.equal(m(x, 500, crf, crl).sample, e0)                   # same tensor objects as the cached ones
+    pri, emb = m.fpg(crl), m.idc(crf)
+    d0 = m.denoiser(x, 250, pri, emb).sample.clone()
+    assert torch.equal(m.denoiser(x, 250, pri, emb).sample, d0)          # cached gates (same objects)
+    pri2 = [p.clone() for p in pri]
+    assert torch.equal(m.denoiser(x, 250, pri2, emb).sample, d0)         # new objects, same values: recomputed, same result
+    pri2[0].mul_(0.5)
+    assert not torch.equal(m.denoiser(x, 250, pri2, emb).sample, d0)     # in-place edit: version counter -> recomputed
+    assert torch.equal(m(x, 500, crf, crl).sample, e0)                   # and the refiner path prepares again after it
+    w2 = dict(weights16)
+    w2["denoiser.ending.bias"] = weights16["denoiser.ending.bias"] + 1.0
+    m.load_state_dict(w2)                                                # live model: a fresh context behind the same object
+    e1 = m(x, 500, crf, crl).sample
+    assert torch.allclose(e1, e0 + 1.0, atol=1e-5)

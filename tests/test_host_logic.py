@@ -127,6 +127,60 @@ def test_bench_self_launches_its_ranks():
     assert "distributed.gather_faces(" in src and src.index("self_launch(_requested_gpus") < src.index("import torch  # noqa")
 
 
+def test_bench_launcher_ends_the_job_when_a_rank_dies_early(tmp_path):
+    """One rank exits before the rendezvous (HD_BENCH_TEST_FAIL_RANK): the launcher names it, shows its stderr, terminates the
+    others and returns non-zero within seconds instead of leaving rank 0 in init_process_group until the driver's timeout.
+    The surviving rank is kept alive artificially (a sleeping stand-in for a worker stuck in the rendezvous)."""
+    import time
+    stub = tmp_path / "bench.py"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("import torch  # noqa: E402")]
+    # the launcher as shipped + a worker body that fails on the marked rank and otherwise hangs like a rank in the rendezvous
+    stub.write_text(head + """
+import time
+if os.environ.get("HD_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK"):
+    sys.stderr.write("bench.py rank %s: exiting early (HD_BENCH_TEST_FAIL_RANK)\\n" % os.environ["RANK"])
+    raise SystemExit(7)
+time.sleep(600)
+""")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HD_BENCH_TEST_FAIL_RANK"] = "2"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(stub), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    dt = time.time() - t0
+    assert r.returncode != 0 and dt < 30, (r.returncode, dt)
+    assert "rank 2 exited with code 7 first" in r.stderr and "exiting early (HD_BENCH_TEST_FAIL_RANK)" in r.stderr, r.stderr
+    assert r.stdout.strip() == ""
+    # the shipped worker has the same early-exit hook and a finite process-group timeout
+    assert 'HD_BENCH_TEST_FAIL_RANK' in src and "timeout=datetime.timedelta" in src
+
+
+def test_vae_accepts_deprecated_attention_key_names():
+    """SD-2.x era VAE checkpoints name the mid-block attention projections query / key / value / proj_attn (as (C, C, 1, 1)
+    convs); diffusers 0.32.2 converts them when loading (the reference loads such a file at test_refiner.py:176-178)."""
+    from hifidiff_amd import arch
+    from hifidiff_amd.vae import AutoencoderKL
+    man = arch.vae_manifest()
+    ren = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    old_sd = {}
+    for k, (shape, _, _) in man.items():
+        nk, sh = k, tuple(shape)
+        for new, old in ren.items():
+            if ".attentions.0." + new + "." in k:
+                nk = k.replace(".attentions.0." + new + ".", ".attentions.0." + old + ".")
+                if k.endswith(".weight"):
+                    sh = sh + (1, 1)
+        old_sd[nk] = torch.zeros(sh)
+    assert any(".query." in k for k in old_sd) and not any(".to_q." in k for k in old_sd)
+    old_sd["metadata_entry"] = "not a tensor"
+    m = AutoencoderKL()
+    res = m.load_state_dict(old_sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert set(m.state_dict()) == set(man)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in old_sd.items() if not k.endswith("proj_attn.bias")})
+
+
 def test_cr_manifest_and_synthetic_weights():
     """CoarseRestoration manifest (checked key-for-key against the reference in oracle/make_golden.py's container run):
     664 tensors, nine STN heads whose synthetic last Linear leans to the identity transform."""
