@@ -38,3 +38,11 @@ def psnr(a, b, data_range=6.0):
     import torch
     mse = float(((torch.as_tensor(a, dtype=torch.float64) - torch.as_tensor(b, dtype=torch.float64)) ** 2).mean())
     return 10.0 * np.log10(data_range ** 2 / max(mse, 1e-30))
+
+
+def psnr_pp(a, b):
+    """PSNR with the GOLDEN's own peak-to-peak as the data range (a fixed range of 6 hides errors on small signals)."""
+    import torch
+    a, b = torch.as_tensor(a, dtype=torch.float64), torch.as_tensor(b, dtype=torch.float64)
+    rng = float(b.max() - b.min())
+    return 10.0 * np.log10(rng ** 2 / max(float(((a - b) ** 2).mean()), 1e-30))

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, golden, psnr, rel_l2
+from conftest import ROOT, golden, psnr, psnr_pp, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -127,7 +127,10 @@ def test_ddim50_against_reference_golden(gpu, model2, inputs2):
     eager = sampling.ddim_sample_eager(model2, x, crf, crl, sch, 50).cpu()
     sch.set_timesteps(50)
     graph = sampling.sample(model2, x, crf, crl, sch).cpu()
-    assert psnr(eager, gd) >= 40.0 and psnr(graph, gd) >= 40.0, (psnr(eager, gd), psnr(graph, gd))
+    # measured (profiles/r03_parity_report.txt): PSNR 53.5 dB on the golden's peak-to-peak (6.0: 13 % of it sits on the +-3 clip),
+    # rel-L2 6.0e-3.  The old bound (40 dB on a fixed range of 6) accepted an RMSE of 0.06 whatever the signal.
+    for got in (eager, graph):
+        assert psnr_pp(got, gd) >= 47.0 and rel_l2(got, gd) <= 2e-2, (psnr_pp(got, gd), rel_l2(got, gd))
     assert psnr(eager, graph) >= 50.0                      # same kernels, per-face vs shared FiLM rows
     assert float(graph.abs().max()) <= 3.0 + 1e-6          # last DDIM step returns the clipped x0
 
@@ -139,7 +142,8 @@ def test_ddpm20_with_given_noise_against_reference_golden(gpu, model2, inputs2):
     sch.timesteps = sch.timesteps[:20]
     noise = T(np.stack([np.stack([synth.ddpm_noise(i, b, 16) for b in range(2)]) for i in range(20)]))
     out = sampling.sample(model2, x, crf, crl, sch, noise=noise).cpu()
-    assert psnr(out, golden("ddpm20_L16.npz")["final"]) >= 40.0
+    g = golden("ddpm20_L16.npz")["final"]
+    assert rel_l2(out, g) <= 1e-3 and psnr_pp(out, g) >= 75.0, (rel_l2(out, g), psnr_pp(out, g))   # measured 2.6e-5 / 107 dB
 
 
 def _philox_normal(seed, step, elems):
@@ -212,7 +216,8 @@ def test_latent32_against_reference_golden(gpu):
     sch.set_timesteps(250)
     sch.timesteps = sch.timesteps[:20]
     lat = sampling.sample(m, x.cuda(), crf.cuda(), crl.cuda(), sch).cpu()
-    assert psnr(lat, golden("ddim250_first20_L32.npz")["final"]) >= 40.0
+    g20 = golden("ddim250_first20_L32.npz")["final"]                      # RMS 0.157: a fixed range of 6 accepted a 38 % error here
+    assert rel_l2(lat, g20) <= 3e-2 and psnr_pp(lat, g20) >= 40.0, (rel_l2(lat, g20), psnr_pp(lat, g20))
 
 
 def test_every_launch_is_reproducible(gpu, weights16):
@@ -334,7 +339,8 @@ def test_unconditional_denoiser_against_reference_golden(gpu, weights16):
     eager = sampling.ddim_sample_eager_unconditional(m, x.cuda(), sch, 10).cpu()
     sch.set_timesteps(10)
     graph = sampling.sample(m, x.cuda(), None, None, sch).cpu()
-    assert psnr(eager, g["ddim10"]) >= 40.0 and psnr(graph, g["ddim10"]) >= 40.0, (psnr(eager, g["ddim10"]), psnr(graph, g["ddim10"]))
+    for got in (eager, graph):
+        assert psnr_pp(got, g["ddim10"]) >= 45.0 and rel_l2(got, g["ddim10"]) <= 3e-2, (psnr_pp(got, g["ddim10"]), rel_l2(got, g["ddim10"]))
     with pytest.raises(RuntimeError):
         sampling.sample(m, x.cuda(), x.cuda(), x.cuda(), sch)      # no conditioning inputs in this mode
 
@@ -563,13 +569,13 @@ def test_ddpm_tail_and_mid_slices_against_reference_golden(gpu, model2):
         x = T(np.stack([np.float32(scale) * synth.randn(f"x_{name}/{f}", (4, 16, 16)) for f in range(2)])).cuda()
         noise = T(np.stack([np.stack([synth.ddpm_noise(first + i, b, 16) for b in range(2)]) for i in range(20)]))
         out = sampling.sample(model2, x, crf, crl, sch, noise=noise).cpu()
-        assert psnr(out, g[name]) >= 40.0, (name, psnr(out, g[name]))
+        assert rel_l2(out, g[name]) <= 1e-3 and psnr_pp(out, g[name]) >= 75.0, (name, rel_l2(out, g[name]), psnr_pp(out, g[name]))   # measured <= 6.1e-5 / >= 100 dB
         if name == "tail":
             lat = x
             for i, t in enumerate(sch.timesteps):
                 eps = model2(lat, torch.full((2,), int(t), device="cuda"), crf, crl).sample
                 lat = sch.step(eps, t, lat, noise=noise[i].cuda()).prev_sample
-            assert psnr(lat.cpu(), g[name]) >= 40.0 and psnr(lat.cpu(), out) >= 50.0
+            assert rel_l2(lat.cpu(), g[name]) <= 1e-3 and psnr(lat.cpu(), out) >= 50.0
             assert float(out.abs().max()) <= 3.0 + 1e-5             # t = 0: x_prev = mu, a blend of the clipped x0 and x
 
 
@@ -754,3 +760,66 @@ def test_submodule_calls_do_not_leave_a_stale_conditioning_cache(gpu, weights16)
     m.load_state_dict(w2)                                                # live model: a fresh context behind the same object
     e1 = m(x, 500, crf, crl).sample
     assert torch.allclose(e1, e0 + 1.0, atol=1e-5)
+
+
+def test_teacher_forced_op_parity(gpu, weights16, model2_launches):
+    """Every launch of one denoiser evaluation against the oracle's arithmetic applied to the launch's OWN inputs (the state
+    the HIP path has reached just before it, read back through hd_debug_read): no inherited drift, so the bound is sharp --
+    fp32 outputs <= 3e-4, bf16-stored outputs <= 3e-3 (measured r03: 7.6e-5 / 4.9e-4 at batch 2, 3.1e-5 / 2.2e-4 at batch 64) --
+    at batch 2 and at the benchmark batch, whose tile shapes differ (16-row tiles, W_NT, CPW = 4, the XCD-affine tile map)."""
+    import op_forced
+    from hifidiff_amd import synth
+    for B in (2, 64):
+        x, crl, crf = synth.sample_inputs(B, 16)
+        rep = []
+        worst = op_forced.forced_scan(model2_launches, weights16, x, crl, crf, 500.0, rep)
+        assert len(rep) >= 200 and not [r for r in rep if "no rule" in r], [r for r in rep if "no rule" in r][:3]
+        assert not [r for r in rep if "<<<<<<" in r], [r for r in rep if "<<<<<<" in r][:8]
+        assert worst["fp32"] <= 3e-4 and worst["bf16"] <= 3e-3, (B, worst)
+
+
+def test_eps_at_the_benchmark_batch_against_oracle(gpu, weights16):
+    """64 faces, the kernel instantiations the benchmark runs (XCD-local stages included), directly against the bf16-emulating
+    oracle: t in {999, 500, 0} with one timestep for all faces, and a timestep per face.  Measured r03: 2.1e-3."""
+    from hifidiff_amd import synth
+    from oracle import hifidiff_oracle as O
+    m = make_model(weights16)
+    x, crl, crf = synth.sample_inputs(64, 16)
+    cond = O.Conditioning(weights16, crl, crf, prec=O.BF16)
+    xd, cld, cfd = x.cuda(), crl.cuda(), crf.cuda()
+    for t in (999, 500, 0):
+        ref = O.fused_denoiser(weights16, x, t, cond=cond, prec=O.BF16)
+        e = m(xd, t, cfd, cld).sample.cpu()
+        assert rel_l2(e, ref) <= 6e-3, (t, rel_l2(e, ref))
+        assert max(rel_l2(e[f], ref[f]) for f in range(64)) <= 8e-3         # no single face carries the error
+    tf = (torch.arange(64) * 37 % 1000).float()
+    ref = O.fused_denoiser(weights16, x, tf, cond=cond, prec=O.BF16)
+    e = m(xd, tf.cuda(), cfd, cld).sample.cpu()
+    assert rel_l2(e, ref) <= 6e-3 and max(rel_l2(e[f], ref[f]) for f in range(64)) <= 8e-3
+
+
+def test_full_trajectories_against_reference_goldens(gpu, weights16, model2, inputs2):
+    """BASELINE configs[1] in miniature: ALL 1000 DDPM steps (clip 3.0, committed-seed noise), B = 2, against the reference
+    network run through the same loop (oracle/make_golden.py --only ddpm1000): the latent after 100 / 500 / 1000 chained
+    bf16-operand steps.  Stated tolerance: rel-L2 <= 1e-2, PSNR >= 55 dB on the golden's peak-to-peak at the end (measured r03:
+    1.3e-3 / 66.1 dB; 7.7e-5 / 97.5 dB after 100 steps).  Then image space: decode through the synthetic-weight VAE (f2, parity
+    unpinned) against the fp32 oracle's decode of the REFERENCE latent: >= 50 dB (measured 61.1)."""
+    from hifidiff_amd import sampling, schedulers, synth
+    from hifidiff_amd.vae import AutoencoderKL
+    from oracle import hifidiff_oracle as O
+    g = golden("ddpm1000_L16.npz")
+    x, crl, crf = [t.cuda() for t in inputs2]
+    noise = T(np.stack([np.stack([synth.ddpm_noise(i, b, 16) for b in range(2)]) for i in range(1000)]))
+    out = None
+    for n, lim_rel, lim_db in ((100, 1e-3, 80.0), (1000, 1e-2, 55.0)):
+        sch = schedulers.DDPMScheduler(clip_sample_range=3.0)
+        sch.timesteps = sch.timesteps[:n]
+        out = sampling.sample(model2, x, crf, crl, sch, noise=noise[:n]).cpu()
+        ref = g[f"step{n}"]
+        assert rel_l2(out, ref) <= lim_rel and psnr_pp(out, ref) >= lim_db, (n, rel_l2(out, ref), psnr_pp(out, ref))
+    assert np.array_equal(g["final"], g["step1000"])
+    PV = synth.vae_state_dict()
+    vae = AutoencoderKL(); vae.load_state_dict(PV); vae.to("cuda:0")
+    img = vae.decode_scaled(out.cuda()).cpu()
+    img_ref = O.vae_decode_scaled(PV, T(g["final"]))
+    assert psnr_pp(img, img_ref) >= 50.0 and rel_l2(img, img_ref) <= 3e-2, (psnr_pp(img, img_ref), rel_l2(img, img_ref))
