@@ -182,3 +182,26 @@ def test_vae_restatement_is_self_consistent():
     assert rel_l2(O.vae_encode_moments(P, x, O.BF16), m) <= 2e-2
     up = O.vae_encode_scaled(P, x, 128, torch.zeros(1, 4, 16, 16), vae_range=True)                  # bicubic 64 -> 128 + to_vae_range
     assert tuple(up.shape) == (1, 4, 16, 16)
+
+
+def test_full_trajectory_goldens_are_reproduced_segment_by_segment(weights16):
+    """ddpm1000_L16.npz / ddim250_L32.npz hold the reference network's latents every 100 / 50 steps of the FULL loops
+    (oracle/make_golden.py --only ddpm1000 | ddim250).  The fp32 oracle, started from one committed checkpoint, reproduces the
+    next one: steps 900 -> 1000 of the DDPM (incl. the no-noise step t = 0) and steps 200 -> 250 of the latent-32 DDIM."""
+    g = golden("ddpm1000_L16.npz")
+    _, crl, crf = synth.sample_inputs(2, 16)
+    sch = O.DDPMScheduler(clip_sample=True, clip_sample_range=3.0)
+    sch.timesteps = sch.timesteps[900:]
+    assert sch.timesteps[0] == 99 and sch.timesteps[-1] == 0
+    noise = lambda i: T(np.stack([synth.ddpm_noise(900 + i, b, 16) for b in range(2)]))  # noqa: E731
+    lat = O.sample(weights16, T(g["step900"]), crf, crl, sch, "ddpm", noise_fn=noise)
+    assert float((lat - T(g["final"])).abs().max()) <= 1e-4
+    assert float(np.abs(g["final"]).max()) <= 3.0 + 1e-5 and float(np.abs(g["step500"]).max()) > 3.0     # x_prev leaves the clip range mid-way
+    g32 = golden("ddim250_L32.npz")
+    P32 = synth.refiner_state_dict(32)
+    _, crl, crf = synth.sample_inputs(1, 32)
+    sch = O.DDIMScheduler(clip_sample=True, clip_sample_range=3.0)
+    sch.set_timesteps(250)
+    sch.timesteps = sch.timesteps[200:]
+    lat = O.sample(P32, T(g32["step200"]), crf, crl, sch, "ddim")
+    assert float((lat - T(g32["final"])).abs().max()) <= 1e-4

@@ -12,9 +12,11 @@ from hifidiff_amd import _lib, refiner, synth
 from tools.op_parity import read_op
 
 
-def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0, per_face=True):
+def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0, per_face=True, only=None):
     """Returns (launches scanned, [(index, name, differing values, max abs difference), ...]).
     which = 0: the denoiser program (one eps evaluation); 1: the conditioning prologue (FPG, ResNet-50 IDC, gates).
+    only: predicate on the launch name (None: every launch); the return count is then the number of launches it selected.
+    Repeats beyond the second compare a SHA-256 of the output on the host, so 300 repeats keep one copy only.
     per_face: a timestep per face (the LayerNorm GEMMs read FiLM rows of the global table: LdF32LNFace) or one for all faces
     (the sampling loop's form: the shared row copied to LDS, LdF32LN) -- different kernels."""
     m = model
@@ -29,17 +31,25 @@ def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0, 
     t = torch.full((B,), 500.0, device="cuda") if per_face else 500.0
     n = L.hd_num_ops(e.ctx, which)
     bad = []
+    scanned = 0
     for i in range(n):
         name = L.hd_debug_op_name(e.ctx, which, i).decode()
+        if only is not None and not only(name):
+            continue
+        scanned += 1
         L.hd_debug_limit_ops(e.ctx, which, i + 1)
         outs = []
-        for _ in range(reps):
+        for r in range(reps):
             if which == 1:
                 e.prepare(crl, cr_face=crf)
             else:
                 e.eps(x, t)
             torch.cuda.synchronize()
-            outs.append(read_op(L, e.ctx, which, i).numpy().copy())
+            o = read_op(L, e.ctx, which, i).numpy()
+            if r < 2 or not np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)):
+                outs.append(o.copy())
+                if r >= 2:
+                    break
         same = all(np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)) for o in outs[1:])
         if not same:
             d = max(float(np.abs(outs[0] - o).max()) for o in outs[1:])
@@ -52,7 +62,7 @@ def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0, 
     L.hd_debug_limit_ops(e.ctx, which, -1)
     if which == 1:
         e.prepare(crl, cr_face=crf)
-    return n, bad
+    return (scanned if only is not None else n), bad
 
 
 def main():
