@@ -16,7 +16,7 @@ def scan(B=64, latent=16, reps=3, model=None, verbose=True, max_bad=5, which=0, 
     """Returns (launches scanned, [(index, name, differing values, max abs difference), ...]).
     which = 0: the denoiser program (one eps evaluation); 1: the conditioning prologue (FPG, ResNet-50 IDC, gates).
     only: predicate on the launch name (None: every launch); the return count is then the number of launches it selected.
-    Repeats beyond the second compare a SHA-256 of the output on the host, so 300 repeats keep one copy only.
+    Repeats beyond the second are compared with the first run and dropped (300 repeats keep two copies only).
     per_face: a timestep per face (the LayerNorm GEMMs read FiLM rows of the global table: LdF32LNFace) or one for all faces
     (the sampling loop's form: the shared row copied to LDS, LdF32LN) -- different kernels."""
     m = model
