@@ -135,6 +135,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 # rocprofv3 --pmc passes of THIS bench command (tools/collect_profiles.sh + tools/pmc_traffic.py).  The file records the
 # hash of the kernel sources it was measured on; `roofline.traffic` is null when that differs from the sources in the tree.
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_latest.json")
+# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass of this command (tools/collect_mfma.sh + tools/pmc_mfma.py), per latent; same hash gate
+MFMA_FILE = os.path.join(ROOT, "profiles", "mfma_latest.json")
 
 
 def kernel_source_hash():
@@ -330,6 +332,11 @@ def main():
             if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("latent") == a.latent and tj.get("kind") == a.kind:
                 traffic, traffic_src = tj["hbm_bytes_per_step"], tj["source"]
                 measured_gbs = round(traffic / step_s / 1e9, 1) if step_s > 0 else None
+        mfma_busy, mfma_src = None, None
+        if os.path.exists(MFMA_FILE) and B == 64 and world == 1:
+            mj = json.load(open(MFMA_FILE)).get("L%d" % a.latent)
+            if mj and mj.get("kernel_source_hash") == kernel_source_hash() and mj.get("kind") == a.kind:
+                mfma_busy, mfma_src = round(mj["mfma_busy_frac"], 4), mj["source"]
         headline = (L == 16 and a.kind == "ddpm" and n_diff == 1000 and B == 64)
         cfg3 = (L == 32 and a.kind == "ddim" and n_diff == 250 and B == 64)
         # which roofline bounds a step: weight streaming (HBM) at latent 16, MFMA at latent 32
@@ -343,7 +350,8 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops_launch,
                      "packed_weight_bytes_counted_by_library": int(wbytes.value),
                      "avg_launch_ms": round(step_ms_avg.value, 4),
-                     "hbm_frac": round(achieved / HBM_PEAK_GBS, 4), "mfma_frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)})
+                     "hbm_frac": round(achieved / HBM_PEAK_GBS, 4), "mfma_frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src})
         res = {
             "metric": "faces/sec (whole node), 16→128 1000-step reverse diffusion, batch 64",
             "value": round(value, 3), "unit": "faces/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -220,16 +220,18 @@ def test_latent32_against_reference_golden(gpu):
     assert rel_l2(lat, g20) <= 3e-2 and psnr_pp(lat, g20) >= 40.0, (rel_l2(lat, g20), psnr_pp(lat, g20))
 
 
-def test_every_launch_is_reproducible(gpu, weights16):
+def test_every_launch_is_reproducible(gpu, weights16, model2_launches):
     """Each launch of the denoiser program, run three times on the same inputs, gives the same bits (fixed reduction orders,
     no float atomics, and no dependence on how loads and LDS returns happen to be timed: the straight-line K loop once
     failed exactly this, in rows 8j+6 / 8j+7 of one tile in one launch out of tens)."""
     import determinism_scan
     m = make_model(weights16)
     n, bad = determinism_scan.scan(64, 16, 3, model=m, verbose=False, per_face=False)   # one timestep for all faces: the sampling loop's kernels
-    assert n > 100 and not bad, bad
-    n, bad = determinism_scan.scan(64, 16, 3, model=m, verbose=False, per_face=True)    # a timestep per face: the LdF32LNFace kernels
-    assert n > 100 and not bad, bad
+    assert n == 75 and not bad, (n, bad)                                               # levels 2 / 3 as four persistent stages
+    n, bad = determinism_scan.scan(64, 16, 3, model=model2_launches, verbose=False, per_face=False)   # ... and as one launch per GEMM
+    assert n == 151 and not bad, (n, bad)
+    n, bad = determinism_scan.scan(64, 16, 3, model=model2_launches, verbose=False, per_face=True)    # a timestep per face: the LdF32LNFace kernels
+    assert n == 151 and not bad, (n, bad)
     n, bad = determinism_scan.scan(64, 16, 2, model=m, verbose=False, which=1)      # the conditioning prologue (FPG, IDC, gates)
     assert n > 100 and not bad, bad
 
