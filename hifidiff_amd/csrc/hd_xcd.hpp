@@ -430,9 +430,10 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             const int ph = 5 * blk;
             if (ph >= P_run) break;
             HD_XSTAMP(0);
-            if (ph > 0) { wait_phase(ph - 1); if (dead) return; if (wave == 0) load_w(B.w1, std::true_type()); }
+            if (ph > 0) { wait_phase(ph - 1); if (dead) return; }
             HD_XSTAMP(1);
-            ln_issue(rs_sx, B.film_off);
+            ln_issue(rs_sx, B.film_off);                                // first: the statistics barrier waits for the slowest wave's partials
+            if (ph > 0 && wave == 0) load_w(B.w1, std::true_type());
             load_a(rs_Xb);
             // per-channel constants of the fused epilogue (weights: plain loads), parked in LDS until the epilogue: 22 values per
             // column (9 + 9 depthwise taps of the two gate halves, their biases, conv1's biases); two loads per thread
@@ -625,9 +626,9 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             if (ph >= P_run) break;
             HD_XSTAMP(0);
             wait_phase(ph - 1); if (dead) return;
-            if (wave == 0) load_w(B.w4, std::true_type());
             HD_XSTAMP(1);
-            ln_issue(rs_sy, B.film_off + 2 * C);
+            ln_issue(rs_sy, B.film_off + 2 * C);                       // first: the statistics barrier waits for the slowest wave's partials
+            if (wave == 0) load_w(B.w4, std::true_type());
             load_a(rs_Yb);
             const float b4a = xs_ldg_f(B.b4 + col), b4b = xs_ldg_f(B.b4 + col + C);
             ln_finish();
