@@ -69,6 +69,7 @@ struct XStageP {
     int force_global;                     // test: use the placement-independent hand-off even when the group shares an XCD
 #ifdef HD_STAMPS
     unsigned long long* stamps;           // [phase][workgroup][8]: 0 start, 1 barrier passed, 2 K loop done, 3 epilogue stores issued, 4 drained, 5 published
+    int dbg_no_a, dbg_no_w;               // timing-only what-ifs (results are garbage): activation loads through zero-record descriptors / no weight loads
 #endif
 };
 
@@ -88,6 +89,10 @@ struct XcdCfg {
     static constexpr int TPR = XS_THREADS / RCU;         // threads per row in the LayerNorm partial merge: 16 / 8
     static constexpr int NIT = RCU * 32 / XS_THREADS;    // tile elements per thread: 2 / 4
     static constexpr int A_WAVE = 32 * LDS_ROW;          // private staging tile of a wave
+    // second half of the next phase's weights: requested behind wave 0's hand-off stores (level 3: 64 KB per workgroup would
+    // otherwise sit in the CU's in-order memory queue ahead of them: 216.9 -> 206.2 us for 8 blocks) or before them (level 2:
+    // 32 KB, where the extra barrier costs more than the queueing: 89.7 vs 92.4 us for 4 blocks)
+    static constexpr bool kStoresFirst = C_ >= 1024;
     static_assert(RSPLIT * NT == XS_GROUP_WG && WMW * WK == 8 && CPW == 2 && S * S == HW, "geometry");
     static_assert(RCU / S * 32 == XS_THREADS, "one (channel, image row) item per thread in the depthwise epilogue");
     static_assert(TPR * 4 >= NT, "partials per thread");
@@ -163,7 +168,11 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
     }
     xs_lds_barrier();
 
+#ifdef HD_STAMPS
+    const size_t act_bytes = p.dbg_no_a ? 0 : (size_t)M * C * 2;    // zero records: the range check drops the loads, the instruction stream stays
+#else
     const size_t act_bytes = (size_t)M * C * 2;
+#endif
     const __amdgpu_buffer_rsrc_t rs_Xb = __builtin_amdgcn_make_buffer_rsrc(p.Xb, 0, (int)act_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_Yb = __builtin_amdgcn_make_buffer_rsrc(p.Yb, 0, (int)act_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_G = __builtin_amdgcn_make_buffer_rsrc(p.G, 0, (int)act_bytes, 0x00020000);
@@ -180,6 +189,9 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
     auto load_w_chunk = [&](const uint4* W, auto pair_c, auto d_c) __attribute__((always_inline)) {
         constexpr bool PAIR = decltype(pair_c)::value;
         constexpr int d = decltype(d_c)::value;
+#ifdef HD_STAMPS
+        if (p.dbg_no_w) return;
+#endif
         const uint4* Wl = W + lane;
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 L.pl[f * 32 + j] = sacc / (float)HW;
             }
             xs_lds_barrier();
-            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.wsca, std::false_type(), std::integral_constant<int, 1>());
+            if constexpr (!K::kStoresFirst) { if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.wsca, std::false_type(), std::integral_constant<int, 1>()); }
             HD_XSTAMP(3);
             if (wave == 0) {
                 if (lane < K::FCU * 4) {
@@ -501,8 +513,10 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                     }
                 }
                 HD_XSTAMP(4);
-                publish(ph);
             }
+            if constexpr (K::kStoresFirst) xs_lds_barrier();          // wave 0's stores are in the queue ahead of the weight requests
+            if constexpr (K::kStoresFirst) { if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.wsca, std::false_type(), std::integral_constant<int, 1>()); }
+            if (wave == 0) publish(ph);
             HD_XSTAMP(5);
         }
         // ======================= q1: s = sca(pooled) ; G <- bf16(G * s) =======================
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 L.pl[tid] = v;
             }
             xs_lds_barrier();
-            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w3, std::false_type(), std::integral_constant<int, 1>());
+            if constexpr (!K::kStoresFirst) { if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w3, std::false_type(), std::integral_constant<int, 1>()); }
             HD_XSTAMP(3);
             if (wave == 0) {
                 // G' = bf16(bf16(g) * s[face]) for this workgroup's tile: 16-byte units (row, 8 columns)
@@ -567,8 +581,10 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 }
                 if (p.S) for (int e = lane; e < K::FCU * 32; e += 64) if (face0 + (e >> 5) < p.B) p.S[(size_t)(face0 + (e >> 5)) * C + ct * 32 + (e & 31)] = L.pl[e];
                 HD_XSTAMP(4);
-                publish(ph);
             }
+            if constexpr (K::kStoresFirst) xs_lds_barrier();          // wave 0's stores are in the queue ahead of the weight requests
+            if constexpr (K::kStoresFirst) { if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w3, std::false_type(), std::integral_constant<int, 1>()); }
+            if (wave == 0) publish(ph);
             HD_XSTAMP(5);
         }
         // ======================= q2: conv3 ; y = x + beta * (.) ; LayerNorm partials =======================
@@ -607,7 +623,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 }
             }
             xs_lds_barrier();
-            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w4, std::true_type(), std::integral_constant<int, 1>());
+            if constexpr (!K::kStoresFirst) { if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w4, std::true_type(), std::integral_constant<int, 1>()); }
             HD_XSTAMP(3);
             if (wave == 0) {
                 for (int u = lane; u < K::RCU * 4; u += 64) {
@@ -616,8 +632,10 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 }
                 for (int r = lane; r < K::RCU; r += 64) if (row0 + r < M) st64(rs_sy, ((row0 + r) * K::NT + ct) * 8, st_out[r]);
                 HD_XSTAMP(4);
-                publish(ph);
             }
+            if constexpr (K::kStoresFirst) xs_lds_barrier();          // wave 0's stores are in the queue ahead of the weight requests
+            if constexpr (K::kStoresFirst) { if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w4, std::true_type(), std::integral_constant<int, 1>()); }
+            if (wave == 0) publish(ph);
             HD_XSTAMP(5);
         }
         // ======================= q3: LN + FiLM -> conv4 -> SimpleGate =======================
@@ -646,7 +664,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 L.gt[e] = f32_to_bf16_bits((v1 + b4a) * (v2 + b4b));
             }
             xs_lds_barrier();
-            if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w5, std::false_type(), std::integral_constant<int, 1>());
+            if constexpr (!K::kStoresFirst) { if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w5, std::false_type(), std::integral_constant<int, 1>()); }
             HD_XSTAMP(3);
             if (wave == 0) {
                 for (int u = lane; u < K::RCU * 4; u += 64) {
@@ -654,8 +672,10 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                     if (row0 + r < M) st128(rs_G, ((row0 + r) * C + ct * 32 + q4 * 8) * 2, *reinterpret_cast<const uint4*>(&L.gt[r * 32 + q4 * 8]));
                 }
                 HD_XSTAMP(4);
-                publish(ph);
             }
+            if constexpr (K::kStoresFirst) xs_lds_barrier();          // wave 0's stores are in the queue ahead of the weight requests
+            if constexpr (K::kStoresFirst) { if (wave != 0 && ph + 1 < P_run) load_w_chunk(B.w5, std::false_type(), std::integral_constant<int, 1>()); }
+            if (wave == 0) publish(ph);
             HD_XSTAMP(5);
         }
         // ======================= q4: conv5 ; x' = y + gamma * (.) ; LayerNorm partials =======================
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 }
             }
             xs_lds_barrier();
-            if (wave != 0 && !last) load_w_chunk(L.blk[blk + 1].w1, std::true_type(), std::integral_constant<int, 1>());
+            if constexpr (!K::kStoresFirst) { if (wave != 0 && !last) load_w_chunk(L.blk[blk + 1].w1, std::true_type(), std::integral_constant<int, 1>()); }
             HD_XSTAMP(3);
             if (wave == 0 && !gated) {
                 for (int u = lane; u < K::RCU * 4; u += 64) {
@@ -731,8 +751,10 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 }
             } else if (wave == 0) {
                 HD_XSTAMP(4);
-                publish(ph);
             }
+            if constexpr (K::kStoresFirst) xs_lds_barrier();          // wave 0's stores are in the queue ahead of the weight requests
+            if constexpr (K::kStoresFirst) { if (wave != 0 && !last) load_w_chunk(L.blk[blk + 1].w1, std::true_type(), std::integral_constant<int, 1>()); }
+            if (wave == 0 && !last) publish(ph);
             HD_XSTAMP(5);
         }
     }

@@ -30,7 +30,7 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale, float o
 template <class T> T* dmalloc(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); return p; }
 
 template <int C, int HW>
-void run(int nblocks, int B, int reps, int force_global) {
+void run(int nblocks, int B, int reps, int force_global, int no_a = 0, int no_w = 0) {
     const int M = B * HW, NT = C / 32;
     std::vector<XBlockW> hb(nblocks);
     unsigned seed = 1;
@@ -56,7 +56,7 @@ void run(int nblocks, int B, int reps, int force_global) {
     p.flags = sync; p.hello = sync + 256; p.gstate = sync + 512;
     unsigned* tmo_h; CK(hipHostMalloc(reinterpret_cast<void**>(&tmo_h), 64, hipHostMallocMapped)); tmo_h[0] = 0;
     CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&p.tmo), tmo_h, 0));
-    p.force_global = force_global;
+    p.force_global = force_global; p.dbg_no_a = no_a; p.dbg_no_w = no_w;
     const int P = 5 * nblocks;
     p.stamps = dmalloc<unsigned long long>((size_t)P * 256 * 8); CK(hipMemset(p.stamps, 0, (size_t)P * 256 * 8 * 8));
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -73,6 +73,7 @@ void run(int nblocks, int B, int reps, int force_global) {
     }
     std::vector<unsigned long long> h((size_t)P * 256 * 8);
     CK(hipMemcpy(h.data(), p.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    if (no_a || no_w) printf("WHAT-IF%s%s (timing only): ", no_a ? " no activation loads" : "", no_w ? " no weight loads" : "");
     printf("C=%d HW=%d blocks=%d B=%d %s: kernel %.1f us = %.2f us per block, %.2f us per phase\n", C, HW, nblocks, B, force_global ? "global hand-off" : "local hand-off",
            best * 1e3, best * 1e3 / nblocks, best * 1e3 / P);
     auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
@@ -104,5 +105,11 @@ int main(int argc, char** argv) {
     run<1024, 4>(8, 64, reps, 0);
     run<512, 16>(4, 64, reps, 0);
     run<1024, 4>(8, 64, reps, 1);
+    run<1024, 4>(8, 64, reps, 0, 1, 0);
+    run<1024, 4>(8, 64, reps, 0, 0, 1);
+    run<1024, 4>(8, 64, reps, 0, 1, 1);
+    run<512, 16>(4, 64, reps, 0, 1, 0);
+    run<512, 16>(4, 64, reps, 0, 0, 1);
+    run<512, 16>(4, 64, reps, 0, 1, 1);
     return 0;
 }
