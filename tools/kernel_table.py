@@ -74,8 +74,32 @@ starts = [i for i, j in zip(intro, intro[1:]) if j - i == n]
 starts = starts[1:] if len(starts) > 2 else starts
 avg = [sum(dur[s + k] for s in starts) / len(starts) for k in range(n)]
 groups = collections.OrderedDict()
-for name, a in zip(ops, avg):
+
+
+def stage_blocks(k, name):
+    """An XCD-local persistent stage (hd_xcd.hpp) appears as ONE launch named after its last block's conv5: levels 2 / 3, and the
+    launch before it is not that block's conv4.  Returns the number of blocks it covers (0: an ordinary launch)."""
     p = name.split(".")
+    if p[0] != "denoiser" or p[-1] != "conv5" or level_of(name) not in (2, 3) or L != 16:
+        return 0
+    if k > 0 and ops[k - 1] == ".".join(p[:-1]) + ".conv4":
+        return 0
+    return int(p[3]) + 1 if p[1] == "encoders" else 2
+
+
+for k, (name, a) in enumerate(zip(ops, avg)):
+    p = name.split(".")
+    nb = stage_blocks(k, name)
+    if nb:
+        key = "L%d %s stage (%d blocks, 1 launch)" % (level_of(name), "enc" if p[1] == "encoders" else "dec", nb)
+        C, HW, M = dims(level_of(name))
+        # per block: 6 C^2 bf16 weights... conv1 2C^2 + sca C^2 + conv3 C^2 + conv4 2C^2 + conv5 C^2 = 7 C^2; activations as the five launches
+        w = nb * 7 * C * C * 2
+        act = nb * sum(op_bytes(".".join(p[:-1]) + "." + q)[1] for q in ("conv2_gate_pool", "sca", "conv3", "conv4"))
+        act += nb * (M * C * 2 + M * C * 4 + M * C * 6)
+        g = groups.setdefault(key, [0, 0.0, 0, 0])
+        g[0] += 1; g[1] += a; g[2] += w; g[3] += act
+        continue
     if p[0] == "denoiser":
         key = "L%d %s" % (level_of(name), p[-1]) if level_of(name) < 4 else "mid %s" % p[-1]
     else:
@@ -84,10 +108,10 @@ for name, a in zip(ops, avg):
     g = groups.setdefault(key, [0, 0.0, 0, 0])
     g[0] += 1; g[1] += a; g[2] += w; g[3] += act
 print("one diffusion step, batch %d, latent %d: %d launches, %.1f us of kernel time (%d steps averaged)" % (B, L, n, sum(avg), len(starts)))
-print("%-22s %4s %10s %10s %9s %9s %8s %10s" % ("launch", "n", "weights MB", "activ. MB", "us each", "us total", "GB/s", "% of 8TB/s"))
+print("%-38s %4s %10s %10s %9s %9s %8s %10s" % ("launch", "n", "weights MB", "activ. MB", "us each", "us total", "GB/s", "% of 8TB/s"))
 tw = ta = tt = 0.0
 for k, (c, t, w, a) in groups.items():
     gbs = (w + a) / c / (t / c) / 1e3
-    print("%-22s %4d %10.2f %10.2f %9.2f %9.1f %8.0f %9.1f%%" % (k, c, w / c / 1e6, a / c / 1e6, t / c, t, gbs, 100 * gbs / PEAK))
+    print("%-38s %4d %10.2f %10.2f %9.2f %9.1f %8.0f %9.1f%%" % (k, c, w / c / 1e6, a / c / 1e6, t / c, t, gbs, 100 * gbs / PEAK))
     tw += w; ta += a; tt += t
-print("%-22s %4d %10.1f %10.1f %9s %9.1f %8.0f %9.1f%%" % ("total", n, tw / 1e6, ta / 1e6, "", tt, (tw + ta) / tt / 1e3, 100 * (tw + ta) / tt / 1e3 / PEAK))
+print("%-38s %4d %10.1f %10.1f %9s %9.1f %8.0f %9.1f%%" % ("total", n, tw / 1e6, ta / 1e6, "", tt, (tw + ta) / tt / 1e3, 100 * (tw + ta) / tt / 1e3 / PEAK))
