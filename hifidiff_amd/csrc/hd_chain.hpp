@@ -247,38 +247,23 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
 
     HD_CSTAMP(5);                                                  // conv4 + gate done
     // ---- conv5 -> x' = y + gamma * (acc + b5): fp32, bf16 copy, LayerNorm partials, optional HCA-gated copy ----
+    // The tile goes back through LDS (in place over y) and leaves in whole 16-byte units: as 4-byte / 2-byte stores per
+    // accumulator element the epilogue was 32-48 store instructions per lane (store-issue bound: 3.2-3.6 us of the kernel).
     {
         f32x16_t accs[MT];
         chain_mma<C, MT>(smem + K::A1_OFF, bw, lane, accs);
         const float bb = c_b5, ga = c_gamma;
+        float2* st_lds = reinterpret_cast<float2*>(smem + K::A2_OFF);           // [BM][NT] partials (the normalised tile is dead)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x16_t& acc = accs[mt];
-            const int rb = row0 + mt * 32;
-            float v[16], gat[16];
-            if (p.outg16) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = rb + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                    const bool ok = full || row < p.M;
-                    const float a = (ok && p.add_src) ? p.add_src[(size_t)row * C + col] : 0.f;
-                    gat[i] = ok ? 1.0f + p.gate_c[(size_t)face * C + col] + p.gate_s[row] : 0.f;   // gates are per launch (chain-local faces)
-                    v[i] = a;
-                }
-            }
+            float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rl = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                const int row = row0 + rl;
-                const float add = p.outg16 ? v[i] : 0.f;
                 v[i] = yt[rl * K::YROW + col] + (acc[i] + bb) * ga;
-                if (full || row < p.M) {
-                    p.Xout[(size_t)row * C + col] = v[i];
-                    if (p.Xout16) p.Xout16[(size_t)row * C + col] = f32_to_bf16_bits(v[i]);
-                    if (p.outg16) p.outg16[(size_t)row * C + col] = f32_to_bf16_bits((v[i] + add) * gat[i]);
-                } else {
-                    v[i] = 0.f;
-                }
+                if (!(full || row0 + rl < p.M)) v[i] = 0.f;
+                yt[rl * K::YROW + col] = v[i];                             // each lane rewrites only what it read
             }
             if (p.stats_out) {
                 float2 ms[16];
@@ -286,11 +271,46 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
                 for (int i = 0; i < 16; ++i) ms[i] = halfwave_mean_m2(v[i]);
                 if ((lane & 31) == kStatLane) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int row = rb + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                        if (full || row < p.M) p.stats_out[(size_t)row * (C / 32) + tile] = ms[i];
-                    }
+                    for (int i = 0; i < 16; ++i) st_lds[(mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * K::NT + tile] = ms[i];
                 }
+            }
+        }
+        __syncthreads();
+        constexpr int UPR = C / 8;                                          // 16-byte bf16 units per row
+        constexpr int kIt = K::BM * UPR / K::THREADS;
+        static_assert(kIt * K::THREADS == K::BM * UPR, "tile / threads");
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int u = tid + it * K::THREADS;
+            const int rl = u / UPR, kq = u - rl * UPR;
+            const int row = row0 + rl;
+            if (full || row < p.M) {
+                const float* xv = yt + rl * K::YROW + kq * 8;
+                const float4 a = *reinterpret_cast<const float4*>(xv), b = *reinterpret_cast<const float4*>(xv + 4);
+                float* xo = p.Xout + (size_t)row * C + kq * 8;
+                *reinterpret_cast<float4*>(xo) = a;
+                *reinterpret_cast<float4*>(xo + 4) = b;
+                const float x8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                if (p.Xout16) *reinterpret_cast<uint4*>(p.Xout16 + (size_t)row * C + kq * 8) = pack8(x8);
+                if (p.outg16) {                                             // f_d * (1 + w_c + w_s) (+ add): the HCA conv input (hca.py:28)
+                    float gv[8];
+                    const float gsr = p.gate_s[row];
+                    const float* gc = p.gate_c + (size_t)face * C + kq * 8;     // gates are per launch (chain-local faces)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float ad = p.add_src ? p.add_src[(size_t)row * C + kq * 8 + i] : 0.f;
+                        gv[i] = (x8[i] + ad) * (1.0f + gc[i] + gsr);
+                    }
+                    *reinterpret_cast<uint4*>(p.outg16 + (size_t)row * C + kq * 8) = pack8(gv);
+                }
+            }
+        }
+        if (p.stats_out) {                                                  // [row][NT] partials: 16 bytes = two partials per store
+            constexpr int SPR = K::NT / 2;
+            for (int u = tid; u < K::BM * SPR; u += K::THREADS) {
+                const int rl = u / SPR, q2 = u - rl * SPR;
+                if (full || row0 + rl < p.M)
+                    *reinterpret_cast<float4*>(p.stats_out + (size_t)(row0 + rl) * K::NT + 2 * q2) = *reinterpret_cast<const float4*>(st_lds + rl * K::NT + 2 * q2);
             }
         }
     }
