@@ -39,11 +39,10 @@
 namespace hd {
 
 // Tile-shape and fusion rules are FIXED in the product.  The HD_* experiment switches that were used to measure them
-//  are read only when HD_EXPERIMENTS=1 is set; otherwise they are inert.  Run-time options that stay:
-// HD_CHAINS (independent sub-batches), HD_TAIL / HD_NO_TAIL (the persistent middle-level kernel).
+//  are read only when HD_EXPERIMENTS=1 is set; otherwise they are inert (HD_CHAINS, independent sub-batches,
+// among them).  The one product switch is HD_NO_XCD=1: levels 2 / 3 as one launch per GEMM instead of XCD-local stages.
 inline const char* hd_env(const char* name) {
-    static const bool on = getenv("HD_EXPERIMENTS") != nullptr;
-    return on ? getenv(name) : nullptr;
+    return getenv("HD_EXPERIMENTS") != nullptr ? getenv(name) : nullptr;
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

@@ -20,7 +20,6 @@
 #include "hd_dispatch.hpp"
 #include "hd_gemm.hpp"
 #include "hd_kernels.hpp"
-#include "hd_tail.hpp"
 #include "hd_vae.hpp"
 #include "hd_xcd.hpp"
 
@@ -206,14 +205,6 @@ struct hd_ctx {
     const void *vae_enc_key[4] = {}, *vae_dec_key[2] = {};
     int vae_enc_flags = -1;
     uint64_t vae_seed = 0;
-
-    // persistent middle-level kernel (hd_tail.hpp): latent 16, batch <= 64, one chain, one FiLM row for all faces
-    bool tail_ok = false;
-    std::vector<TailBlockW> tail_blocks;
-    TailBlockW* tail_blocks_dev = nullptr;
-    uint4* tail_act = nullptr; float2* tail_stats = nullptr; unsigned *tail_flags = nullptr, *tail_state = nullptr;
-    unsigned* tail_tmo_host = nullptr;        // pinned, device-mapped: non-zero after a hand-off wait gave up
-    unsigned* tail_tmo_dev = nullptr;
 
     // XCD-local persistent stages (hd_xcd.hpp): latent 16, batch <= 64, one chain, one FiLM row for all faces
     struct XStage { XBlockW* blocks_dev = nullptr; unsigned* sync = nullptr; int nblocks = 0; };   // sync: flags | hello | gstate, 256 words each
@@ -1105,7 +1096,6 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
 }
 
 int build_denoiser_program(hd_ctx* c);
-int setup_mid_tail(hd_ctx* c);
 int get_xstage(hd_ctx* c, int first_block, int nblocks, hd_ctx::XStage** out);
 int setup_xcd(hd_ctx* c);
 
@@ -1124,7 +1114,7 @@ int alloc_workspace(hd_ctx* c, int B) {
 }
 int alloc_workspace_new(hd_ctx* c, int B) {
     int n = 1;                                            // measured: per-kernel cost barely depends on M, so more chains only add launches
-    if (const char* e = getenv("HD_CHAINS")) n = atoi(e);
+    if (const char* e = hd_env("HD_CHAINS")) n = atoi(e);         // experiment switch (needs HD_EXPERIMENTS=1): measured slower at 2 and 4
     if (n < 1) n = 1;
     if (n > 8) n = 8;
     while (n > 1 && B % n != 0) --n;
@@ -1219,36 +1209,9 @@ int build_denoiser_program(hd_ctx* c) {
     // x + idc_conv(id) -> HCA0 (model.py:245-247): the add and the gate are applied by the last mid block's conv5 epilogue.
     // The unconditional Denoiser (model.py:117-128) has neither: the up-convs read the blocks' own bf16 output.
     const bool cond = c->conditional;
-    const int mid_np = np;
-    auto mid_ops = std::make_shared<std::vector<Op>>();                // the middle level as one launch per GEMM
     for (int j = 0; j < 8; ++j) {
         GateOut g0; g0.gate_c = c->ch->gate_c[0]; g0.gate_s = c->ch->gate_s[0]; g0.add = c->ch->idc_term;
-        add_naf_block(c, c->tail_ok ? *mid_ops : prog, c->den_blocks[bi++], c->ch->lv[4], nullptr, &np, &cnt, (cond && j == 7) ? &g0 : nullptr);
-    }
-    if (c->tail_ok) {
-        // ... and as ONE persistent launch (hd_tail.hpp) when its conditions hold at run time: batch <= 64, a single chain
-        // (every workgroup must be resident: nothing else may occupy CUs), one FiLM row for all faces
-        const Level& lv = c->ch->lv[4];
-        TailP tp{};
-        tp.M = lv.M; tp.nblocks = 8; tp.blocks = c->tail_blocks_dev;
-        tp.X = lv.X; tp.Xb = lv.Xb; tp.sx = lv.sx; tp.sx_np = mid_np; tp.ln_eps = 1e-6f;
-        tp.Xout = lv.X;
-        if (cond) { tp.outg16 = lv.Xg; tp.gate_c = c->ch->gate_c[0]; tp.gate_s = c->ch->gate_s[0]; tp.add_src = c->ch->idc_term; }
-        else { tp.Xout16 = lv.Xb; tp.stats_out = lv.sx; }
-        tp.act = c->tail_act; tp.stats = c->tail_stats; tp.flags = c->tail_flags; tp.state = c->tail_state; tp.tmo = c->tail_tmo_dev;
-        const bool shape_ok = lv.M <= 64 && lv.H == 1 && (mid_np == 64 || mid_np == 16);
-        Op op;
-        op.name = "denoiser.middle_blks.7.conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
-        op.run = [c, chp, tp, mid_ops, shape_ok](hipStream_t s) -> hipError_t {
-            if (shape_ok && c->tail_ok && c->chains.size() == 1 && c->film_face_stride == 0) {
-                TailP r = tp;
-                r.film = c->film_from_cur ? chp->film_cur : c->film_table;
-                return launch_mid_tail(r, s);
-            }
-            for (auto& o : *mid_ops) { const hipError_t e = o.run(s); if (e != hipSuccess) return e; }
-            return hipSuccess;
-        };
-        prog.push_back(op);
+        add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[4], nullptr, &np, &cnt, (cond && j == 7) ? &g0 : nullptr);
     }
     if (cond) add_hca(c, prog, "hcas.0", c->hca[0], c->ch->lv[4].Xg, c->ch->lv[4].Y, c->ch->lv[4].Yb, c->ch->lv[4].M, c->ch->lv[4].H);
     for (int i = 0; i < 4; ++i) {
@@ -1724,76 +1687,6 @@ static int build_vae_decode(hd_ctx* c, int B, int L, const float* latents, float
     return HD_OK;
 }
 
-// Persistent middle level (hd_tail.hpp): second packing of the 8 middle blocks' 1x1 weights in the 16x16x32 B-fragment
-// order, the blocks' pointer table and the hand-off workspace (sized for 64 rows: independent of the batch).
-static int pack_frag16(hd_ctx* c, const std::string& name, const uint4** out) {
-    const RawTensor* w = find_raw(c, name + ".weight");
-    if (!w) HD_FAIL(c, HD_ERR_WEIGHTS, "missing %s.weight", name.c_str());
-    PackF16P q{};
-    q.src = w->dev; q.N = (int)w->shape[0]; q.K = (int)w->shape[1];
-    q.KH = w->shape.size() == 4 ? (int)w->shape[2] : 1; q.KW = w->shape.size() == 4 ? (int)w->shape[3] : 1;
-    if (q.N % 16 || q.K % 32) HD_FAIL(c, HD_ERR_WEIGHTS, "%s: shape not tileable for the persistent kernel", name.c_str());
-    const size_t n16 = (size_t)(q.N / 16) * (q.K / 32) * 64;
-    int rc = dev_alloc(c, &q.dst, n16);
-    if (rc) return rc;
-    hipLaunchKernelGGL(pack_weight_frag16_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 65535)), dim3(256), 0, 0, q);
-    HIPCHECK(c, hipGetLastError());
-    *out = q.dst;
-    return HD_OK;
-}
-int setup_mid_tail(hd_ctx* c) {
-    c->tail_ok = false;
-    // Opt-in (HD_TAIL=1): measured on MI355X the persistent form is SLOWER than one launch per GEMM (13.5 vs 8.9 us per
-    // phase, profiles/r02_tail_kernel_stamps.txt): every hand-off costs two memory round trips plus the skew
-    // of 16 producers (3.4 us) and a drained write-through publish (1.1 us), more than the 1.6 us kernel boundary it replaces.
-    if (c->S != 1 || !getenv("HD_TAIL") || getenv("HD_NO_TAIL")) return HD_OK;   // latent 16 only: one pixel per face at the middle level
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || prop.multiProcessorCount < TL_WG) return HD_OK;   // every workgroup must be resident
-    int rc = 0;
-    for (int j = 0; j < 8; ++j) {
-        const std::string p = "denoiser.middle_blks." + std::to_string(j);
-        const BlockW& bw = c->den_blocks[c->den_block_index[p]];
-        if (bw.C != TL_C) return HD_OK;
-        TailBlockW t{};
-        rc |= pack_frag16(c, p + ".conv1", &t.w1); rc |= pack_frag16(c, p + ".sca.1", &t.wsca); rc |= pack_frag16(c, p + ".conv3", &t.w3);
-        rc |= pack_frag16(c, p + ".conv4", &t.w4); rc |= pack_frag16(c, p + ".conv5", &t.w5);
-        if (rc) return rc;
-        t.b1 = bw.conv1.bias; t.bsca = bw.sca.bias; t.b3 = bw.conv3.bias; t.b4 = bw.conv4.bias; t.b5 = bw.conv5.bias;
-        t.beta = bw.beta; t.gamma = bw.gamma;
-        t.dw_c = bw.dw_wT + (size_t)4 * 2 * TL_C;                       // centre tap of the tap-major copy [9][2C]
-        t.dw_b = bw.dw_b;
-        t.film_off = bw.film_off;
-        c->tail_blocks.push_back(t);
-    }
-    rc |= dev_alloc(c, &c->tail_blocks_dev, c->tail_blocks.size());
-    rc |= dev_alloc(c, &c->tail_act, TL_SLABS * TL_SLAB_U4); rc |= dev_alloc(c, &c->tail_stats, TL_SLABS * TL_STAT_F2);
-    rc |= dev_alloc(c, &c->tail_flags, (size_t)5 * TL_MAXBLK * TL_WG); rc |= dev_alloc(c, &c->tail_state, 64);
-    if (rc) return rc;
-    HIPCHECK(c, hipMemcpy(c->tail_blocks_dev, c->tail_blocks.data(), c->tail_blocks.size() * sizeof(TailBlockW), hipMemcpyHostToDevice));
-    HIPCHECK(c, hipMemset(c->tail_act, 0, TL_SLABS * TL_SLAB_U4 * sizeof(uint4)));
-    HIPCHECK(c, hipMemset(c->tail_stats, 0, TL_SLABS * TL_STAT_F2 * sizeof(float2)));
-    HIPCHECK(c, hipMemset(c->tail_flags, 0, (size_t)5 * TL_MAXBLK * TL_WG * sizeof(unsigned)));
-    HIPCHECK(c, hipMemset(c->tail_state, 0, 64 * sizeof(unsigned)));
-    HIPCHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->tail_tmo_host), 64, hipHostMallocMapped));
-    c->tail_tmo_host[0] = 0;
-    HIPCHECK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->tail_tmo_dev), c->tail_tmo_host, 0));
-    c->tail_ok = true;
-    return HD_OK;
-}
-// A hand-off wait of the persistent kernel gave up (a workgroup was not resident, or a fault): results since then are
-// garbage.  Reported once; the context then falls back to one launch per GEMM.
-static int check_tail(hd_ctx* c) {
-    if (c->tail_tmo_host && c->tail_tmo_host[0]) {
-        const unsigned code = c->tail_tmo_host[0];
-        c->tail_tmo_host[0] = 0;
-        c->tail_ok = false; c->graphs_valid = false;
-        for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
-        HD_FAIL(c, HD_ERR_HIP, "persistent middle-level kernel: a hand-off wait timed out (code 0x%x); results of the last call are invalid, "
-                               "falling back to one launch per GEMM", code);
-    }
-    return HD_OK;
-}
-
 // XCD-local persistent stages (hd_xcd.hpp): usable when every one of the 256 workgroups gets a CU of its own (8 XCDs x 32
 // CUs) and the level geometry is the latent-16 one (4 / 16 pixels per face at levels 3 / 2).  HD_NO_XCD=1 builds the
 // program without them.
@@ -1971,7 +1864,7 @@ void hd_destroy(hd_ctx* c) {
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->film_ev) (void)hipEventDestroy(c->film_ev);
     for (auto& sg : c->stage) { if (sg.ev) (void)hipEventDestroy(sg.ev); if (sg.host) (void)hipHostFree(sg.host); }
-    if (c->tail_tmo_host) (void)hipHostFree(c->tail_tmo_host);
+    if (c->xcd_tmo_host) (void)hipHostFree(c->xcd_tmo_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto& kv : c->ws_cache) destroy_saved(kv.second);
@@ -2056,8 +1949,6 @@ int hd_finalize_weights(hd_ctx* c) {
         c->den_blocks.push_back(bw);
     }
     c->film_total = off;
-    rc = setup_mid_tail(c);
-    if (rc) return rc;
     rc = setup_xcd(c);
     if (rc) return rc;
     off = 0;
@@ -2332,8 +2223,6 @@ int hd_scheduler_step(float* x_inout, const float* eps, const float* coef7, cons
 int hd_eps(hd_ctx* c, const float* x, const float* timesteps, int n_t, float* eps_out, void* stream) {
     int rc = check_ready(c, true);
     if (rc) return rc;
-    rc = check_tail(c);
-    if (rc) return rc;
     rc = check_xcd(c);
     if (rc) return rc;
     if (!x || !timesteps || !eps_out || (n_t != 1 && n_t != c->B)) HD_FAIL(c, HD_ERR_INVALID, "hd_eps: bad arguments (n_t must be 1 or batch)");
@@ -2361,8 +2250,6 @@ int hd_eps(hd_ctx* c, const float* x, const float* timesteps, int n_t, float* ep
 
 int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* noise, uint64_t seed, void* stream) {
     int rc = check_ready(c, true);
-    if (rc) return rc;
-    rc = check_tail(c);
     if (rc) return rc;
     rc = check_xcd(c);
     if (rc) return rc;

@@ -249,12 +249,13 @@ def test_full_batch_properties(gpu, weights16):
     assert bool(torch.isfinite(a).all()) and float((a - x).abs().mean()) > 1e-3
     c = sampling.sample(m, x, crf, crl, sch, seed=12)
     assert not torch.equal(a, c)                               # the device noise depends on the seed
-    os.environ["HD_CHAINS"] = "2"                              # two sub-batches on two streams (default: one chain)
+    os.environ["HD_EXPERIMENTS"] = "1"                         # experiment switch: two sub-batches on two streams (default: one chain)
+    os.environ["HD_CHAINS"] = "2"
     try:
         m1 = make_model(weights16)
         a1 = sampling.sample(m1, x, crf, crl, sch, seed=11)
     finally:
-        del os.environ["HD_CHAINS"]
+        del os.environ["HD_CHAINS"], os.environ["HD_EXPERIMENTS"]
     assert psnr(a1.cpu(), a.cpu()) >= 50.0                     # same faces, same noise indices, different tiling only
     m2 = make_model(weights16)                                 # faces 0,1 sampled alone: noise indices differ -> use DDIM
     d = schedulers.DDIMScheduler(clip_sample_range=3.0); d.set_timesteps(50); d.timesteps = d.timesteps[:10]
@@ -595,36 +596,6 @@ def test_coarse_restoration_strong_warps_against_reference_golden(gpu):
     out = m(x.cuda()).cpu()
     assert rel_l2(out, g["out"]) <= 1e-2
     assert rel_l2(out, O.coarse_restoration(P, x, prec=O.BF16)) <= 6e-3
-
-
-def test_persistent_middle_level_against_per_gemm_launches(gpu, weights16):
-    """The 8 middle blocks as ONE persistent launch (hd_tail.hpp: LDS-DMA weight ring, sc1 hand-offs with per-workgroup
-    flags) against the same blocks as 40 launches (HD_NO_TAIL): same arithmetic, different MFMA shape and K split, so
-    agreement to accumulation order; bitwise reproducible; falls back (bit-identically) for per-face timesteps."""
-    from hifidiff_amd import _lib, sampling, schedulers, synth
-    os.environ["HD_TAIL"] = "1"                                          # opt-in: measured slower than the launches (DESIGN.md §5)
-    try:
-        m = make_model(weights16)
-    finally:
-        del os.environ["HD_TAIL"]
-    m0 = make_model(weights16)
-    L = _lib.lib()
-    for B in (5, 64):                                                   # ragged rows in the last row group; the benchmark batch
-        x, crl, crf = [t.cuda() for t in synth.sample_inputs(B, 16)]
-        e1 = m(x, 500, crf, crl).sample
-        n1 = L.hd_num_ops(m.engine.ctx, 0)
-        e0 = m0(x, 500, crf, crl).sample
-        assert n1 == L.hd_num_ops(m0.engine.ctx, 0) - 39                # 40 launches became one
-        assert rel_l2(e1.cpu(), e0.cpu()) <= 3e-3, (B, rel_l2(e1.cpu(), e0.cpu()))
-        assert torch.equal(m(x, 500, crf, crl).sample, e1)              # fixed reduction orders: reproducible
-        tf = torch.arange(B, device="cuda") * 7 % 1000                  # per-face FiLM rows: the per-GEMM launches run instead
-        assert torch.equal(m(x, tf, crf, crl).sample, m0(x, tf, crf, crl).sample)
-    sch = schedulers.DDPMScheduler(clip_sample_range=3.0)
-    sch.timesteps = sch.timesteps[:8]
-    a = sampling.sample(m, x, crf, crl, sch, seed=3)
-    b = sampling.sample(m, x, crf, crl, sch, seed=3)
-    c0 = sampling.sample(m0, x, crf, crl, sch, seed=3)
-    assert torch.equal(a, b) and psnr(a.cpu(), c0.cpu()) >= 50.0
 
 
 def test_vae_boundary_against_oracle(gpu):

@@ -29,7 +29,7 @@
 //
 // Measured on MI355X (tools/persist_bench.hip, profiles/r02_persist_proto_*): see DESIGN.md §5.
 #pragma once
-#include "hd_gemm.hpp"
+#include "../../hifidiff_amd/csrc/hd_gemm.hpp"
 
 namespace hd {
 

@@ -7,7 +7,7 @@
 #include <vector>
 #include <algorithm>
 #define HD_STAMPS 1
-#include "../hifidiff_amd/csrc/hd_tail.hpp"
+#include "experiments/hd_tail.hpp"
 using namespace hd;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
