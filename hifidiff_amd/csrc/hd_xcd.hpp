@@ -85,7 +85,7 @@ struct XcdCfg {
     static constexpr int CPW = C / 64 / WK;              // 64-deep chunks per wave: 2 / 2
     static constexpr int KS = C / 16;                    // k-steps of a K = C GEMM
     static constexpr int FCU = RCU / HW;                 // faces per workgroup: 8 / 4
-    static constexpr int S = (HW == 4) ? 2 : (HW == 16) ? 4 : (HW == 64) ? 8 : 1;   // face side
+    static constexpr int S = (HW == 4) ? 2 : (HW == 16) ? 4 : (HW == 64) ? 8 : (HW == 256) ? 16 : 1;   // face side
     static constexpr int TPR = XS_THREADS / RCU;         // threads per row in the LayerNorm partial merge: 16 / 8
     static constexpr int NIT = RCU * 32 / XS_THREADS;    // tile elements per thread: 2 / 4
     static constexpr int A_WAVE = 32 * LDS_ROW;          // private staging tile of a wave
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             // (2) depthwise 3x3 (pad 1) on both halves, SimpleGate, gate tile (bf16) -> LDS
             {
                 const int j = tid & 31, rr = tid >> 5;
-                constexpr int ls = (K::S == 2) ? 1 : (K::S == 4) ? 2 : (K::S == 8) ? 3 : 0;
+                constexpr int ls = (K::S == 2) ? 1 : (K::S == 4) ? 2 : (K::S == 8) ? 3 : (K::S == 16) ? 4 : 0;
                 const int p0 = rr << ls;
                 const int y = (p0 & (HW - 1)) >> ls;
                 const float rsum = dw_gate_row<K::S>(red + j, red + K::RCU * 32 + j, p0, y > 0, y < K::S - 1, dw_wa, dw_wb, dw_ba, dw_bb,

@@ -102,6 +102,8 @@ void run(int nblocks, int B, int reps, int force_global, int no_a = 0, int no_w 
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
+    run<256, 64>(2, 64, reps, 0);
+    run<128, 256>(2, 64, reps, 0);
     run<1024, 4>(8, 64, reps, 0);
     run<512, 16>(4, 64, reps, 0);
     run<1024, 4>(8, 64, reps, 1);
