@@ -1,0 +1,471 @@
+// hd_face.hpp — a run of ConditionalNAFBlocks of a SHALLOW level (level 0: C = 128, 16 x 16 faces; level 1: C = 256, 8 x 8) as
+// ONE launch, rows split over the workgroups of a face (gfx950 only).
+//
+// At these levels a block is row-local except for two things (models/denoiser/conditional_naf.py:108-136): the depthwise
+// 3x3 conv2 reads the image rows above and below (:116), and the SCA pool averages over the whole face (:119).  A workgroup
+// owns 32 pixel rows of one face (2 image rows at level 0, 4 at level 1) and ALL channels, one 32-column tile per wave as in
+// hd_chain.hpp; the residual stream tile (x -> y -> x') lives in LDS for the whole run.  Per block the workgroups of a face
+// (8 at level 0, 2 at level 1: a "cluster") meet twice:
+//   A  x' rows of the previous block are published (fp32, the level's X buffer) -> the neighbours' boundary image rows are
+//      read back, LayerNorm2d + FiLM is applied to own + halo rows, conv1 runs on 32 + 2S rows, so that the depthwise conv of
+//      the own rows finds its halo in LDS (recomputing conv1 for the halo instead of exchanging T1: half the exchanged bytes,
+//      and the exchange then sits at the block boundary where x' has to leave anyway);
+//   B  per-workgroup channel sums of the gate -> the face's pooled mean.
+// Everything else is the chain kernel's arithmetic (hd_chain.hpp): SCA GEMV on the MFMA, G * s, conv3, y, LayerNorm (two-pass,
+// fp32 statistics, bf16 value), conv4, SimpleGate, conv5, x'.  Replaces 2 launches per block (fused conv1, chain kernel).
+//
+// Hand-off (MI355X_MICROARCH.md "Valid forms" row 1, placement-independent): hand-off data is stored write-through (sc1) by
+// every wave, every storing wave drains (s_waitcnt vmcnt(0)), the workgroup's barrier, ONE lane stores the workgroup's flag
+// (sc1); a consumer polls the cluster's flags (one line per face) with sc1 loads and, after its workgroup barrier, reads the
+// handed-off rows with sc1 loads only.  Flags carry an epoch the kernel advances itself (launch counter per face).  The
+// members of a cluster get block ids that are equal mod 8 (one XCD under round-robin dispatch: speed only).  Every spin is
+// bounded; all workgroups of a face must be resident (512 workgroups at two per CU at level 0, 128 at level 1).
+#pragma once
+#include "hd_chain.hpp"
+#include "hd_xcd.hpp"
+
+namespace hd {
+
+struct FStageP {
+    int B, nblocks;                        // faces (<= 64), blocks of this run
+    const XBlockW* blocks;                 // device array [nblocks]
+    float* X;                              // [M][C] fp32: entry, per-block hand-off of x', exit
+    unsigned short* Xb;                    // exit: bf16 copy of x' (what the down conv gathers), or NULL
+    unsigned short* outg16; const float *gate_c, *gate_s;     // exit: (x') * (1 + w_c + w_s) for the HCA conv, or NULL
+    float* pool_part;                      // [faces][CL][C] channel sums of the gate of each workgroup's rows
+    const float* film; float ln_eps;
+    unsigned *flags, *gstate;              // [64 faces][16] words each
+    unsigned* tmo;
+    int block_limit;                       // introspection: stop after this many blocks (<= 0: all)
+#ifdef HD_STAMPS
+    unsigned long long* stamps;            // [block][workgroup][8]
+#endif
+};
+#ifdef HD_STAMPS
+#define HD_FSTAMP(i) do { if (p.stamps && tid == 0) p.stamps[((size_t)blk * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HD_FSTAMP(i) do { } while (0)
+#endif
+
+template <int C>
+struct FaceCfg {
+    static constexpr int S = (C == 128) ? 16 : 8;              // face side
+    static constexpr int HW = S * S, CL = HW / 32, RI = 32 / S;   // pixels per face, workgroups per face, image rows per workgroup
+    static constexpr int NT = C / 32, THREADS = 64 * NT, KS = C / 16;
+    static constexpr int AROW = C * 2 + 16;                    // bytes per bf16 tile row (padded)
+    static constexpr int XROW = C + 4;                         // floats per fp32 tile row (padded)
+    static constexpr int XT_OFF = 0;                           // x / y / x' tile fp32 [32][XROW]
+    static constexpr int ALN_OFF = XT_OFF + 32 * XROW * 4;     // LayerNorm output bf16 [64][AROW]: rows 0..31 own, 32.. above halo, 32+S.. below
+    static constexpr int A1_OFF = ALN_OFF + 32 * AROW;         // gate tile bf16 [32][AROW]: rows 32..63 of the LN tile (the halo rows are dead once
+                                                               // conv1 has run; a barrier separates the two uses) -> two workgroups per CU at C = 128
+    static constexpr int T1_OFF = ALN_OFF + 64 * AROW;         // per wave: conv1 half tile fp32 [64][32]
+    static constexpr int SV_OFF = T1_OFF + NT * 64 * 32 * 4;   // sca vector [C]
+    static constexpr int GB_OFF = SV_OFF + C * 4;              // FiLM gain | bias of norm1 and norm2 [4][C]
+    static constexpr int PL_OFF = GB_OFF + 4 * C * 4;          // pooled mean [C]
+    static constexpr int PP_OFF = PL_OFF + C * 4;              // this workgroup's channel sums [C]
+    static constexpr int SMEM = PP_OFF + C * 4;
+    static_assert(32 + 2 * S <= 64, "own + halo rows fit two MFMA row tiles");
+};
+
+typedef __attribute__((address_space(1))) unsigned fs_gu32;
+
+// all B fragments of one column tile (K = C); the pointer comes from the LDS copy of the block table: say it is global
+template <int C>
+__device__ __forceinline__ void face_load_b(const uint4* W, int tile, int lane, uint4* b) {
+    const uint4* Wl = W + (size_t)tile * (C / 16) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < C / 16; ++ks) b[ks] = xs_ldg_u4(Wl + ks * 64);
+}
+
+template <int C>
+__global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kernel(const FStageP p) {      // two waves per SIMD: two 4-wave workgroups per CU at C = 128
+    typedef FaceCfg<C> K;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ XBlockW s_blk[XS_MAXBLK];
+    __shared__ unsigned s_abort, s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
+    const int fl = jj / K::CL, kk = jj - fl * K::CL;
+    const int face = xcd * 8 + fl;
+    if (face >= p.B) return;                                        // nobody of this face takes part
+    const int M = p.B * K::HW;
+    const int row0 = face * K::HW + kk * 32;                        // own rows
+    const bool has_up = kk > 0, has_dn = kk < K::CL - 1;
+    const int tile = wave, col = tile * 32 + (lane & 31);
+    float* xt = reinterpret_cast<float*>(smem + K::XT_OFF);
+    float* s_vec = reinterpret_cast<float*>(smem + K::SV_OFF);
+    float* gb = reinterpret_cast<float*>(smem + K::GB_OFF);
+    float* pooled = reinterpret_cast<float*>(smem + K::PL_OFF);
+    float* poolp = reinterpret_cast<float*>(smem + K::PP_OFF);
+    float* t1w = reinterpret_cast<float*>(smem + K::T1_OFF) + wave * 64 * 32;
+
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(p.blocks);
+        unsigned* dst = reinterpret_cast<unsigned*>(s_blk);
+        for (int i = tid; i < p.nblocks * (int)(sizeof(XBlockW) / 4); i += K::THREADS) dst[i] = src[i];
+        if (tid == 0) {
+            s_abort = 0u;
+            s_base = __hip_atomic_load((fs_gu32*)(p.gstate + face * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 64u;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_X = __builtin_amdgcn_make_buffer_rsrc(p.X, 0, (int)((size_t)M * C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_PP = __builtin_amdgcn_make_buffer_rsrc(p.pool_part, 0, p.B * K::CL * C * 4, 0x00020000);
+    fs_gu32* flags = (fs_gu32*)(p.flags + face * 16);
+
+    // ---- entry: own rows of x (written by the previous launch) ----
+    for (int u = tid; u < 32 * (C / 4); u += K::THREADS) {
+        const int r = u / (C / 4), q = u - r * (C / 4);
+        *reinterpret_cast<float4*>(xt + r * K::XROW + q * 4) = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + q * 4);
+    }
+    __syncthreads();
+    const unsigned base = s_base;
+    bool dead = false;
+
+    // publish: every storing wave has drained, then one lane stores the flag; wait: wave 0 polls the cluster's flags
+    auto publish = [&](unsigned value) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + kk, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto poll = [&](unsigned value, unsigned code) __attribute__((always_inline)) {
+        if (wave == 0) {
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned v = lane < K::CL ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : value;
+                if (__all((int)(v - value) >= 0)) break;
+                if (spins > XS_SPINS) {
+                    if (lane == 0) { s_abort = 1u; __hip_atomic_store((fs_gu32*)p.tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    };
+    auto wait_for = [&](unsigned value, unsigned code) __attribute__((always_inline)) {
+        if (wave == 0) {
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned v = lane < K::CL ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : value;
+                if (__all((int)(v - value) >= 0)) break;
+                if (spins > XS_SPINS) {
+                    if (lane == 0) { s_abort = 1u; __hip_atomic_store((fs_gu32*)p.tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        dead = s_abort != 0u;
+    };
+    // LayerNorm2d + FiLM of one row held by a group of 16 lanes: two-pass fp32 statistics, the bf16 copy is what is normalised
+    // (utils.py:16-24, conditional_naf.py:114-115,126-127; same rounding points as hd_chain.hpp)
+    constexpr int V4 = C / 64;                                       // float4 per lane per row
+    auto ln_row = [&](const float4 (&v)[V4], const float* g, const float* b, char* dst_row, bool valid) __attribute__((always_inline)) {
+        const int l16 = lane & 15;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = row16_sum(sum) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / C) + p.ln_eps);
+        const float nmr = -mean * rstd;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            const int k = 4 * l16 + 64 * i;
+            const float x4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xq = bf16_bits_to_f32(f32_to_bf16_bits(x4[e]));
+                o[e] = valid ? fmaf(fmaf(xq, rstd, nmr), g[k + e], b[k + e]) : 0.f;
+            }
+            *reinterpret_cast<uint2*>(dst_row + k * 2) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+        }
+    };
+
+    const int nb_run = (p.block_limit > 0 && p.block_limit < p.nblocks) ? p.block_limit : p.nblocks;
+    uint4 bw[K::KS], bw2[K::KS];
+    for (int blk = 0; blk < nb_run; ++blk) {
+        const XBlockW& B = s_blk[blk];
+        HD_FSTAMP(0);
+        // ---- FiLM rows of both LayerNorms: requested by waves 1.. (wave 0 polls), copied to LDS behind the hand-off wait ----
+        float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);                // [bias_att | gain_att | bias_ffn | gain_ffn] at film_off: 4C floats
+        const int gi = tid - 64;
+        static_assert(K::THREADS - 64 >= C, "one float4 of the FiLM rows per thread of waves 1..");
+        if (gi >= 0 && gi < C) gbv = *reinterpret_cast<const float4*>(p.film + B.film_off + 4 * gi);
+        face_load_b<C>(B.w1, tile, lane, bw);
+        if constexpr (C == 128) face_load_b<C>(B.w1, tile + K::NT, lane, bw2);    // C = 256: one gate half at a time (registers)
+        // per-channel constants of the depthwise stage: requested with the weights at C = 128; at C = 256 the two weight sets
+        // already hold half the register file, so they (and the next GEMMs' weights) wait until conv1 has consumed them
+        constexpr bool kEarly = C == 128;
+        float c_b1a = 0.f, c_b1b = 0.f, dwa[9], dwb[9], dba = 0.f, dbb = 0.f;
+        auto load_dw_consts = [&]() __attribute__((always_inline)) {
+            c_b1a = xs_ldg_f(B.b1 + col); c_b1b = xs_ldg_f(B.b1 + col + C);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { dwa[t] = xs_ldg_f(B.dw_w + (size_t)t * 2 * C + col); dwb[t] = xs_ldg_f(B.dw_w + (size_t)t * 2 * C + col + C); }
+            dba = xs_ldg_f(B.dw_b + col); dbb = xs_ldg_f(B.dw_b + col + C);
+        };
+        if constexpr (kEarly) load_dw_consts();
+        // ---- A: the neighbours' boundary rows of x' (previous block of this launch, or the previous launch) ----
+        if (blk > 0) poll(base + 2u * (unsigned)(blk - 1) + 2u, 0x200u + (unsigned)blk);
+        if (gi >= 0 && gi < C) *reinterpret_cast<float4*>(gb + 4 * gi) = gbv;   // gb[0..C) bias1, [C..2C) gain1, [2C..3C) bias2, [3C..4C) gain2
+        __syncthreads();
+        if (s_abort) return;
+        {
+            const int l16 = lane & 15;
+            constexpr int ROWS = 32 + 2 * K::S;
+            constexpr int HRI = (ROWS - 32 + K::NT * 4 - 1) / (K::NT * 4);      // halo rows per 16-lane group
+            float4 hv[HRI][V4];
+            bool hok[HRI];
+#pragma unroll
+            for (int hi = 0; hi < HRI; ++hi) {                           // requested first: they arrive while the own rows are normalised
+                const int r = 32 + hi * K::NT * 4 + wave * 4 + (lane >> 4);
+                const bool up = r < 32 + K::S;
+                hok[hi] = r < ROWS && (up ? has_up : has_dn);
+                const int grow = up ? row0 - K::S + (r - 32) : row0 + 32 + (r - 32 - K::S);
+                const int gr = hok[hi] ? grow : row0;
+#pragma unroll
+                for (int i = 0; i < V4; ++i) {
+                    const xs_u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_X, (gr * C + 4 * l16 + 64 * i) * 4, 0, 16);
+                    hv[hi][i] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+                }
+            }
+            for (int r = wave * 4 + (lane >> 4); r < 32; r += K::NT * 4) {
+                float4 v[V4];
+#pragma unroll
+                for (int i = 0; i < V4; ++i) v[i] = *reinterpret_cast<const float4*>(xt + r * K::XROW + 4 * l16 + 64 * i);
+                ln_row(v, gb + C, gb, smem + K::ALN_OFF + r * K::AROW, true);
+            }
+#pragma unroll
+            for (int hi = 0; hi < HRI; ++hi) {
+                const int r = 32 + hi * K::NT * 4 + wave * 4 + (lane >> 4);
+                if (r < ROWS) ln_row(hv[hi], gb + C, gb, smem + K::ALN_OFF + r * K::AROW, hok[hi]);
+            }
+        }
+        __syncthreads();
+        HD_FSTAMP(1);
+        // ---- conv1 on own + halo rows: column tile j and j + C/32 (the two SimpleGate halves) ----
+        f32x16_t acc_a[2], acc_b[2];
+        chain_mma<C, 2>(smem + K::ALN_OFF, bw, lane, acc_a);
+        if constexpr (kEarly) {
+            chain_mma<C, 2>(smem + K::ALN_OFF, bw2, lane, acc_b);
+            face_load_b<C>(B.wsca, tile, lane, bw);      // the next GEMMs' weights fly during the depthwise stage
+            face_load_b<C>(B.w3, tile, lane, bw2);
+        } else {
+            face_load_b<C>(B.w1, tile + K::NT, lane, bw);                         // second half's weights fly during the first half's depthwise pass
+            load_dw_consts();
+        }
+        // ---- depthwise 3x3 (pad 1) of the own rows, half by half through the wave's LDS tile; SimpleGate ----
+        HD_FSTAMP(2);
+        float u1[16], u2[16];
+        auto dw_half = [&](const f32x16_t (&acc)[2], float bias1, const float (&w)[9], float bias2, float (&u)[16]) __attribute__((always_inline)) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    t1w[r * 32 + (lane & 31)] = acc[mt][i] + bias1;
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int j = lane & 31, h = lane >> 5;
+            constexpr int S = K::S, IRL = K::RI / 2;                  // image rows per lane: 1 (level 0) or 2 (level 1)
+#pragma unroll
+            for (int q = 0; q < IRL; ++q) {
+                const int ir = h * IRL + q;                           // image row inside the workgroup's 32 rows
+                // three image rows x (S + 2) columns, zero outside the face
+                float v[3][S + 2];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) { v[rr][0] = 0.f; v[rr][S + 1] = 0.f; }
+                const bool up_in = ir > 0, dn_in = ir < K::RI - 1;
+                const bool up_ok = up_in || has_up, dn_ok = dn_in || has_dn;
+                const int up_base = up_in ? (ir - 1) * S : 32, dn_base = dn_in ? (ir + 1) * S : 32 + S;
+#pragma unroll
+                for (int x = 0; x < S; ++x) {
+                    v[0][x + 1] = up_ok ? t1w[(up_base + x) * 32 + j] : 0.f;
+                    v[1][x + 1] = t1w[(ir * S + x) * 32 + j];
+                    v[2][x + 1] = dn_ok ? t1w[(dn_base + x) * 32 + j] : 0.f;
+                }
+#pragma unroll
+                for (int x = 0; x < S; ++x) {
+                    float a = bias2;
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        a = fmaf(w[rr * 3], v[rr][x], a); a = fmaf(w[rr * 3 + 1], v[rr][x + 1], a); a = fmaf(w[rr * 3 + 2], v[rr][x + 2], a);
+                    }
+                    u[q * S + x] = a;
+                }
+            }
+        };
+        dw_half(acc_a, c_b1a, dwa, dba, u1);
+        if constexpr (!kEarly) {
+            chain_mma<C, 2>(smem + K::ALN_OFF, bw, lane, acc_b);
+            face_load_b<C>(B.wsca, tile, lane, bw);                  // conv3's weights follow after the depthwise pass (registers)
+        }
+        dw_half(acc_b, c_b1b, dwb, dbb, u2);
+        if constexpr (!kEarly) face_load_b<C>(B.w3, tile, lane, bw2);
+        __syncthreads();                                             // every wave has read the halo rows of the LN tile: the gate tile overwrites them
+        {
+            const int j = lane & 31, h = lane >> 5;
+            constexpr int IRL = K::RI / 2;
+            float rsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < IRL; ++q)
+#pragma unroll
+                for (int x = 0; x < K::S; ++x) {
+                    const float g = u1[q * K::S + x] * u2[q * K::S + x];
+                    rsum += g;
+                    const int r = (h * IRL + q) * K::S + x;
+                    *reinterpret_cast<unsigned short*>(smem + K::A1_OFF + r * K::AROW + (tile * 32 + j) * 2) = f32_to_bf16_bits(g);
+                }
+            const float other = __shfl_xor(rsum, 32);
+            if (h == 0) poolp[tile * 32 + j] = rsum + other;          // rows of image-row group 0 first, then group 1
+        }
+        __syncthreads();
+        HD_FSTAMP(3);
+        // ---- B: channel sums of the face ----
+        if (tid < C / 4) {
+            const float4 v = *reinterpret_cast<const float4*>(poolp + 4 * tid);
+            const xs_u32x4 x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(x, rs_PP, ((face * K::CL + kk) * C + 4 * tid) * 4, 0, 16);
+        }
+        publish(base + 2u * (unsigned)blk + 1u);
+        wait_for(base + 2u * (unsigned)blk + 1u, 0x300u + (unsigned)blk);
+        if (dead) return;
+        if (tid < C / 4) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < K::CL; ++m) {                          // fixed order: every workgroup of the face gets the same bits
+                const xs_u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_PP, ((face * K::CL + m) * C + 4 * tid) * 4, 0, 16);
+                s.x += __uint_as_float(raw.x); s.y += __uint_as_float(raw.y); s.z += __uint_as_float(raw.z); s.w += __uint_as_float(raw.w);
+            }
+            const float inv = 1.0f / (float)K::HW;
+            *reinterpret_cast<float4*>(pooled + 4 * tid) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+        }
+        const float c_bsca = xs_ldg_f(B.bsca + col), c_b3 = xs_ldg_f(B.b3 + col), c_beta = xs_ldg_f(B.beta + col), c_b4a = xs_ldg_f(B.b4 + col),
+                    c_b4b = xs_ldg_f(B.b4 + col + C), c_b5 = xs_ldg_f(B.b5 + col), c_gamma = xs_ldg_f(B.gamma + col);
+        __syncthreads();
+        HD_FSTAMP(4);
+        // ---- SCA: s = Wsca * pooled + b on the MFMA (row 0 of the A tile holds the pooled vector) ----
+        {
+            f32x16_t acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < K::KS; ++ks) {
+                const float* q = pooled + ks * 16 + 8 * (lane >> 5);
+                const float4 v0 = *reinterpret_cast<const float4*>(q), v1 = *reinterpret_cast<const float4*>(q + 4);
+                const uint4 r0 = make_uint4(pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w));
+                const uint4 a = (lane & 31) == 0 ? r0 : make_uint4(0, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw[ks]), acc, 0, 0, 0);
+            }
+            if (lane < 32) s_vec[col] = acc[0] + c_bsca;
+        }
+        face_load_b<C>(B.w4, tile, lane, bw);
+        __syncthreads();
+        // ---- A1 <- bf16(bf16(g) * s) in place ----
+        for (int u = tid; u < 32 * (C / 8); u += K::THREADS) {
+            const int r = u / (C / 8), q = u - r * (C / 8);
+            uint4* gp = reinterpret_cast<uint4*>(smem + K::A1_OFF + r * K::AROW + q * 16);
+            float v[8];
+            unpack8(*gp, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= s_vec[q * 8 + i];
+            *gp = pack8(v);
+        }
+        __syncthreads();
+        // ---- conv3 -> y = x + beta * (acc + b3), in place over x ----
+        {
+            f32x16_t acc[1];
+            chain_mma<C, 1>(smem + K::A1_OFF, bw2, lane, acc);
+            face_load_b<C>(B.w4, tile + K::NT, lane, bw2);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                xt[r * K::XROW + col] = xt[r * K::XROW + col] + (acc[0][i] + c_b3) * c_beta;
+            }
+        }
+        __syncthreads();
+        // ---- LayerNorm + FiLM on y -> rows 0..31 of the LN tile ----
+        {
+            const int l16 = lane & 15;
+            for (int r = wave * 4 + (lane >> 4); r < 32; r += K::NT * 4) {
+                float4 v[V4];
+#pragma unroll
+                for (int i = 0; i < V4; ++i) v[i] = *reinterpret_cast<const float4*>(xt + r * K::XROW + 4 * l16 + 64 * i);
+                ln_row(v, gb + 3 * C, gb + 2 * C, smem + K::ALN_OFF + r * K::AROW, true);
+            }
+        }
+        __syncthreads();
+        // ---- conv4 (both halves) -> SimpleGate -> A1 ----
+        {
+            f32x16_t a1[1], a2[1];
+            chain_mma<C, 1>(smem + K::ALN_OFF, bw, lane, a1);
+            chain_mma<C, 1>(smem + K::ALN_OFF, bw2, lane, a2);
+            face_load_b<C>(B.w5, tile, lane, bw);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                *reinterpret_cast<unsigned short*>(smem + K::A1_OFF + r * K::AROW + col * 2) = f32_to_bf16_bits((a1[0][i] + c_b4a) * (a2[0][i] + c_b4b));
+            }
+        }
+        __syncthreads();
+        // ---- conv5 -> x' = y + gamma * (acc + b5), in place ----
+        {
+            f32x16_t acc[1];
+            chain_mma<C, 1>(smem + K::A1_OFF, bw, lane, acc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                xt[r * K::XROW + col] = xt[r * K::XROW + col] + (acc[0][i] + c_b5) * c_gamma;
+            }
+        }
+        __syncthreads();
+        HD_FSTAMP(5);
+        // ---- x' leaves: fp32 rows for the neighbours' halo (and the next launch); at the end of the run the bf16 / gated copies ----
+        const bool last = blk == nb_run - 1;
+        for (int u = tid; u < 32 * (C / 8); u += K::THREADS) {
+            const int r = u / (C / 8), q = u - r * (C / 8);
+            const float* xv = xt + r * K::XROW + q * 8;
+            const float4 a = *reinterpret_cast<const float4*>(xv), b = *reinterpret_cast<const float4*>(xv + 4);
+            const int off = ((row0 + r) * C + q * 8) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128((xs_u32x4){__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)}, rs_X, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128((xs_u32x4){__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)}, rs_X, off + 16, 0, 16);
+            if (last) {
+                const float x8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                const size_t o = (size_t)(row0 + r) * C + q * 8;
+                if (p.Xb) *reinterpret_cast<uint4*>(p.Xb + o) = pack8(x8);
+                if (p.outg16 && blk == p.nblocks - 1) {                // f_d * (1 + w_c + w_s): the HCA conv input (hca.py:28)
+                    float gv[8];
+                    const float gsr = p.gate_s[row0 + r];
+                    const float* gc = p.gate_c + (size_t)face * C + q * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) gv[i] = x8[i] * (1.0f + gc[i] + gsr);
+                    *reinterpret_cast<uint4*>(p.outg16 + o) = pack8(gv);
+                }
+            }
+        }
+        if (!last) publish(base + 2u * (unsigned)blk + 2u);
+        HD_FSTAMP(6);
+    }
+    if (kk == 0 && tid == 0) __hip_atomic_store((fs_gu32*)(p.gstate + face * 16), base / 64u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int C>
+inline hipError_t launch_face_stage(const FStageP& p, hipStream_t s) {
+    typedef FaceCfg<C> K;
+    if (p.B < 1 || p.B > 64 || p.nblocks < 1 || p.nblocks > XS_MAXBLK) return hipErrorInvalidValue;
+    static bool granted = false;
+    if (!granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&naf_face_stage_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+        if (e != hipSuccess) return e;
+        granted = true;
+    }
+    hipLaunchKernelGGL((naf_face_stage_kernel<C>), dim3(64 * K::CL), dim3(K::THREADS), K::SMEM, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace hd

@@ -22,6 +22,7 @@
 #include "hd_kernels.hpp"
 #include "hd_vae.hpp"
 #include "hd_xcd.hpp"
+#include "hd_face.hpp"
 
 using namespace hd;
 
@@ -212,6 +213,11 @@ struct hd_ctx {
     bool xcd_ok = false;                      // the device and the network allow it (setup_xcd)
     bool xcd_on = true;                       // run-time switch (hd_set_option "xcd"): off = the per-GEMM launches of the same program
     int xcd_phase_limit = 0, xcd_force_global = 0;
+    // face-cluster persistent stages of the shallow levels (hd_face.hpp): sync words [flags | gstate] and the pool exchange buffer
+    struct FStage { unsigned* sync = nullptr; float* pool_part = nullptr; };
+    std::map<int, FStage> fstages;            // by index of the stage's first block
+    bool face_on = true;                      // run-time switch (hd_set_option "face")
+    int face_block_limit = 0;
     unsigned* xcd_tmo_host = nullptr;         // pinned, device-mapped: non-zero after a hand-off wait gave up
     unsigned* xcd_tmo_dev = nullptr;
 
@@ -1199,9 +1205,52 @@ int build_denoiser_program(hd_ctx* c) {
         };
         prog.push_back(op);
     };
+    // Levels 0 / 1 (latent 16, batch <= 64): a run of blocks as ONE launch with the rows of a face split over a cluster of
+    // workgroups (hd_face.hpp); the per-block launches (fused conv1 + chain kernel) stay as the other form of the same op.
+    static const bool no_face = getenv("HD_NO_FACE") != nullptr || getenv("HD_NO_XCD") != nullptr;
+    auto add_face_stage = [&](int nblk, const Level& lv, const GateOut* gate, bool want_xb) {
+        const int first = bi;
+        const bool shape_ok = c->xcd_ok && !no_face && B <= 64 && ((lv.C == 128 && lv.H == 16) || (lv.C == 256 && lv.H == 8)) && nblk <= XS_MAXBLK && !(gate && gate->add);
+        auto sub = std::make_shared<std::vector<Op>>();
+        for (int j = 0; j < nblk; ++j)
+            add_naf_block(c, shape_ok ? *sub : prog, c->den_blocks[bi++], lv, nullptr, &np, &cnt, (gate && j == nblk - 1) ? gate : nullptr);
+        if (!shape_ok) return;
+        hd_ctx::XStage* xs = nullptr;
+        stage_rc = get_xstage(c, first, nblk, &xs);
+        if (stage_rc) return;
+        hd_ctx::FStage& fs = c->fstages[first];
+        if (!fs.sync) {
+            const bool ws = c->ws_scope;
+            c->ws_scope = false;
+            int rc = dev_alloc(c, &fs.sync, (size_t)2 * 64 * 16);
+            rc |= dev_alloc(c, &fs.pool_part, (size_t)64 * 8 * 256);
+            c->ws_scope = ws;
+            if (rc || hipMemset(fs.sync, 0, (size_t)2 * 64 * 16 * sizeof(unsigned)) != hipSuccess) { stage_rc = HD_ERR_HIP; return; }
+        }
+        FStageP fp{};
+        fp.B = B; fp.nblocks = nblk; fp.blocks = xs->blocks_dev;
+        fp.X = lv.X; fp.Xb = want_xb ? lv.Xb : nullptr; fp.ln_eps = 1e-6f;
+        if (gate) { fp.outg16 = lv.Xg; fp.gate_c = gate->gate_c; fp.gate_s = gate->gate_s; }
+        fp.pool_part = fs.pool_part; fp.flags = fs.sync; fp.gstate = fs.sync + 64 * 16; fp.tmo = c->xcd_tmo_dev;
+        const bool c128 = lv.C == 128;
+        Op op;
+        op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
+        op.run = [c, chp, fp, sub, c128](hipStream_t s) -> hipError_t {
+            if (c->xcd_ok && c->face_on && c->chains.size() == 1 && c->film_face_stride == 0) {
+                FStageP r = fp;
+                r.film = c->film_from_cur ? chp->film_cur : c->film_table;
+                r.block_limit = c->face_block_limit;
+                return c128 ? launch_face_stage<128>(r, s) : launch_face_stage<256>(r, s);
+            }
+            for (auto& o : *sub) { const hipError_t e = o.run(s); if (e != hipSuccess) return e; }
+            return hipSuccess;
+        };
+        prog.push_back(op);
+        np = lv.C / 32; cnt = 32;
+    };
     for (int l = 0; l < 4; ++l) {
         if (l >= 2) add_stage(enc[l], c->ch->lv[l], nullptr);
-        else for (int j = 0; j < enc[l]; ++j) add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[l], nullptr, &np, &cnt);
+        else add_face_stage(enc[l], c->ch->lv[l], nullptr, true);
         if (stage_rc) return stage_rc;
         add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
         np = c->ch->lv[l + 1].C / 32; cnt = 32;
@@ -1226,7 +1275,8 @@ int build_denoiser_program(hd_ctx* c) {
             add_stage(2, lo, cond ? &g : nullptr);
             if (stage_rc) return stage_rc;
         } else {
-            for (int j = 0; j < 2; ++j) add_naf_block(c, prog, c->den_blocks[bi++], lo, nullptr, &np, &cnt, (cond && j == 1) ? &g : nullptr);
+            add_face_stage(2, lo, cond ? &g : nullptr, !cond);          // unconditional: the up conv / ending read the blocks' own output
+            if (stage_rc) return stage_rc;
         }
         if (cond) add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
     }
@@ -1736,6 +1786,8 @@ static int check_xcd(hd_ctx* c) {
         c->xcd_on = false; c->graphs_valid = false;
         for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
         for (auto& kv : c->xstages) (void)hipMemset(kv.second.sync, 0, (size_t)3 * 256 * sizeof(unsigned));
+        for (auto& kv : c->fstages) (void)hipMemset(kv.second.sync, 0, (size_t)2 * 64 * 16 * sizeof(unsigned));
+        c->face_on = false;
         HD_FAIL(c, HD_ERR_HIP, "persistent XCD stage: a hand-off wait timed out (code 0x%x); results of the last call are invalid, "
                                "falling back to one launch per GEMM", code);
     }
@@ -2430,6 +2482,8 @@ int hd_set_option(hd_ctx* c, const char* key, int value) {
     if (k == "xcd") c->xcd_on = value != 0;
     else if (k == "xcd_phase_limit") c->xcd_phase_limit = value;
     else if (k == "xcd_force_global") c->xcd_force_global = value;
+    else if (k == "face") c->face_on = value != 0;
+    else if (k == "face_block_limit") c->face_block_limit = value;
     else HD_FAIL(c, HD_ERR_INVALID, "unknown option %s", key);
     c->graphs_valid = false;                               // captured graphs hold the old choice
     for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
@@ -2440,6 +2494,7 @@ int hd_get_option(hd_ctx* c, const char* key) {
     const std::string k = key;
     if (k == "xcd") return (c->xcd_ok && c->xcd_on) ? 1 : 0;
     if (k == "xcd_stages") return (int)c->xstages.size();
+    if (k == "face_stages") return (int)c->fstages.size();
     return HD_ERR_INVALID;
 }
 
