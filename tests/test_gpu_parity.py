@@ -655,7 +655,7 @@ def test_xcd_stages_match_the_per_gemm_launches_bit_for_bit(gpu, weights16):
         x, crl, crf = [t.cuda() for t in synth.sample_inputs(B, 16)]
         _opt(m, "xcd", 1)
         e1 = m(x, 500, crf, crl).sample.clone()
-        assert L.hd_get_option(m.engine.ctx, b"xcd") == 1 and L.hd_get_option(m.engine.ctx, b"xcd_stages") == 4
+        assert L.hd_get_option(m.engine.ctx, b"xcd") == 1 and L.hd_get_option(m.engine.ctx, b"xcd_stages") == 8    # block tables of the 4 + 4 stages
         assert L.hd_num_ops(m.engine.ctx, 0) == 63                     # 151 launches with one per GEMM: 80 became 4 (levels 2 / 3), 16 became 4 (levels 0 / 1)
         assert torch.equal(m(x, 500, crf, crl).sample, e1)              # reproducible
         _opt(m, "xcd_force_global", 1)
