@@ -77,12 +77,13 @@ groups = collections.OrderedDict()
 
 
 def stage_blocks(k, name):
-    """An XCD-local persistent stage (hd_xcd.hpp) appears as ONE launch named after its last block's conv5: levels 2 / 3, and the
-    launch before it is not that block's conv4.  Returns the number of blocks it covers (0: an ordinary launch)."""
+    """A persistent stage (hd_xcd.hpp at levels 2 / 3, hd_face.hpp at levels 0 / 1) appears as ONE launch named after its last
+    block's conv5, and the launch before it does not belong to that block.  Returns the number of blocks it covers (0: an
+    ordinary launch)."""
     p = name.split(".")
-    if p[0] != "denoiser" or p[-1] != "conv5" or level_of(name) not in (2, 3) or L != 16:
+    if p[0] != "denoiser" or p[-1] != "conv5" or level_of(name) > 3 or L != 16:
         return 0
-    if k > 0 and ops[k - 1] == ".".join(p[:-1]) + ".conv4":
+    if k > 0 and ops[k - 1].startswith(".".join(p[:-1]) + "."):
         return 0
     return int(p[3]) + 1 if p[1] == "encoders" else 2
 
@@ -93,10 +94,13 @@ for k, (name, a) in enumerate(zip(ops, avg)):
     if nb:
         key = "L%d %s stage (%d blocks, 1 launch)" % (level_of(name), "enc" if p[1] == "encoders" else "dec", nb)
         C, HW, M = dims(level_of(name))
-        # per block: 6 C^2 bf16 weights... conv1 2C^2 + sca C^2 + conv3 C^2 + conv4 2C^2 + conv5 C^2 = 7 C^2; activations as the five launches
+        # per block: conv1 2C^2 + sca C^2 + conv3 C^2 + conv4 2C^2 + conv5 C^2 = 7 C^2 bf16 weights; activations as the launches it replaces
         w = nb * 7 * C * C * 2
-        act = nb * sum(op_bytes(".".join(p[:-1]) + "." + q)[1] for q in ("conv2_gate_pool", "sca", "conv3", "conv4"))
-        act += nb * (M * C * 2 + M * C * 4 + M * C * 6)
+        if C <= 256:                       # conv1, depthwise+gate, then the chain launch (op_bytes of "conv5" at these levels)
+            act = nb * sum(op_bytes(".".join(p[:-1]) + "." + q)[1] for q in ("conv1", "conv2_gate_pool", "conv5"))
+        else:
+            act = nb * sum(op_bytes(".".join(p[:-1]) + "." + q)[1] for q in ("conv2_gate_pool", "sca", "conv3", "conv4"))
+            act += nb * (M * C * 2 + M * C * 4 + M * C * 6)
         g = groups.setdefault(key, [0, 0.0, 0, 0])
         g[0] += 1; g[1] += a; g[2] += w; g[3] += act
         continue
