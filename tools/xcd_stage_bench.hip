@@ -3,13 +3,18 @@
 // launches, then per phase the median over workgroups of: barrier wait, K loop (A loads + LayerNorm + MFMA), epilogue,
 // store drain, publish; and the span of the phase over the whole chip.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHD_STAMPS -o tools/xcd_stage_bench_bin tools/xcd_stage_bench.hip
+//        (-DXS_EXPERIMENT_PASSES [-DXS_PASS_ROWS=64]: `xcd_stage_bench_bin 20 32` times the archived multi-pass form at latent 32, level 3)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#ifdef XS_EXPERIMENT_PASSES          // the multi-pass generalisation tried for latent 32, level 3 (tools/experiments/README.md)
+#include "experiments/hd_xcd_passes.hpp"
+#else
 #include "../hifidiff_amd/csrc/hd_xcd.hpp"
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 using namespace hd;
@@ -102,8 +107,15 @@ void run(int nblocks, int B, int reps, int force_global, int no_a = 0, int no_w 
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
-    run<256, 64>(2, 64, reps, 0);
-    run<128, 256>(2, 64, reps, 0);
+#ifdef XS_EXPERIMENT_PASSES
+    if (argc > 2 && atoi(argv[2]) == 32) {          // latent 32, level 3: 128 rows per workgroup in passes of XS_PASS_ROWS (32 or 64) rows
+        run<1024, 16>(8, 64, reps, 0);
+        run<1024, 16>(2, 64, reps, 0);
+        run<1024, 16>(8, 64, reps, 0, 1, 0);
+        run<1024, 16>(8, 64, reps, 0, 0, 1);
+        return 0;
+    }
+#endif
     run<1024, 4>(8, 64, reps, 0);
     run<512, 16>(4, 64, reps, 0);
     run<1024, 4>(8, 64, reps, 1);
