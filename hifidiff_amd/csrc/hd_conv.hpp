@@ -31,12 +31,16 @@ struct ConvP {
     unsigned short* out16;            // bf16 copy or NULL
 };
 
-template <int C_, int S_, int BM_, int MT_, int KS_, int DEPTH_ = 8>
+// STRIP: faces too large for LDS (32x32 pixels at level 0 of latent 32).  A workgroup's BM rows are whole image rows of one
+// face; it stages them plus the image row above and the one below (rows outside the face are never read: their taps
+// point at the zero row).
+template <int C_, int S_, int BM_, int MT_, int KS_, int DEPTH_ = 8, bool STRIP_ = false>
 struct ConvCfg {
     static constexpr int C = C_, S = S_, HW = S_ * S_, BM = BM_, MT = MT_, KS = KS_;
+    static constexpr bool STRIP = STRIP_;
     static constexpr int RG = BM / (32 * MT);                    // row groups
     static constexpr int WAVES = RG * KS, THREADS = 64 * WAVES;
-    static constexpr int NP = BM > HW ? BM : HW;                 // staged pixels: whole faces covering the BM rows
+    static constexpr int NP = STRIP ? BM + 2 * S : (BM > HW ? BM : HW);   // staged pixels: whole faces covering the BM rows / the strip and its halo
     static constexpr int ROWB = C * 2 + 16;                      // bytes per staged pixel (padded against bank conflicts)
     static constexpr int KSTEPS = 9 * C / 16;                    // k-steps of the whole K = 9*C
     static constexpr int SPT = C / 16, CPW = SPT / KS;           // k-steps per tap: all channels / this wave's slice
@@ -49,6 +53,7 @@ struct ConvCfg {
     static_assert(NSTEP >= DEPTH, "prefetch ring longer than the loop");
     static_assert(SPT % KS == 0 && BM % (32 * MT) == 0, "shape");
     static_assert((HW >= BM && HW % BM == 0) || (BM % HW == 0), "row tiles are whole faces or a face is whole row tiles");
+    static_assert(!STRIP || (BM % S == 0 && HW % BM == 0 && HW > BM), "a strip is whole image rows of one face");
 };
 
 template <class K>
@@ -66,7 +71,7 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
         tile = (j / (int)gridDim.x) * 8 + (lin & 7);
     }
     const int row0 = bx * K::BM;
-    const int pix0 = (row0 / K::NP) * K::NP;                       // first staged pixel (face aligned)
+    const int pix0 = K::STRIP ? row0 - S : (row0 / K::NP) * K::NP;   // first staged pixel (face aligned / one image row above the strip: may lie outside the face)
     // weights first: independent of everything else.  Step n = tap * CPW + j reads k-step tap * SPT + ksl * CPW + j.
     uint4 bq[K::DEPTH];
     const uint4* Wl = p.W + ((size_t)tile * K::KSTEPS + ksl * K::CPW) * 64 + lane;
@@ -79,25 +84,28 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
     // ---- stage the faces (16-byte pieces, whole lines) and the zero row ----
     {
         constexpr int PPR = C / 8;                                 // pieces per pixel
-        const uint4* src = reinterpret_cast<const uint4*>(p.X + (size_t)pix0 * C);
+        const uint4* src = reinterpret_cast<const uint4*>(p.X) + (long long)pix0 * PPR;
         // all loads first, then all LDS stores: written as one loop the compiler kept it rolled, one load -> wait -> store
         // per trip, i.e. eight serial round trips ahead of the first MFMA (6 of the kernel's 12 us).  The address is clamped
         // and the value masked instead of the load being predicated, so that nothing sits under a branch.
         constexpr int NIT = (K::NP * PPR + K::THREADS - 1) / K::THREADS;
         static_assert(NIT <= 16, "staging registers");
         uint4 stage[NIT];
-        const int last = (p.M - pix0) * PPR - 1;                   // last valid piece of this workgroup's faces (>= 0: row0 < M)
+        // strip: pieces of the halo rows that fall outside the strip's face are clamped into it and zeroed (never read anyway)
+        const int first = K::STRIP ? ((row0 / HW) * HW - pix0) * PPR : 0;
+        const int last = K::STRIP ? ((row0 / HW + 1) * HW - pix0) * PPR - 1
+                                  : (p.M - pix0) * PPR - 1;        // last valid piece of this workgroup's faces (>= 0: row0 < M)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * K::THREADS;
-            stage[it] = src[i <= last ? i : last];
+            stage[it] = src[i > last ? last : (i < first ? first : i)];
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * K::THREADS;
             if ((K::NP * PPR) % K::THREADS == 0 || i < K::NP * PPR) {
                 const int px = i / PPR, q = i - px * PPR;
-                *reinterpret_cast<uint4*>(smem + px * K::ROWB + q * 16) = i <= last ? stage[it] : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(smem + px * K::ROWB + q * 16) = (i <= last && i >= first) ? stage[it] : make_uint4(0, 0, 0, 0);
             }
         }
         for (int i = tid; i < K::ROWB / 16; i += K::THREADS) *reinterpret_cast<uint4*>(smem + K::NP * K::ROWB + i * 16) = make_uint4(0, 0, 0, 0);
@@ -108,13 +116,15 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int pl = (row0 - pix0) + (rg * MT + mt) * 32 + r;                 // staged-pixel index of this row
+            // staged-pixel index of this row; strip: pixel index inside the face, staged index = that - (first pixel of the strip) + S
+            const int pl = (K::STRIP ? row0 % HW : row0 - pix0) + (rg * MT + mt) * 32 + r;
             const int f = pl / HW, rem = pl - f * HW, y = rem / S, x = rem - y * S;
+            const int sbase = K::STRIP ? S - row0 % HW : f * HW;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
                 const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
-                src_off[mt][t] = (in ? (f * HW + yy * S + xx) : K::NP) * K::ROWB + h * 16;
+                src_off[mt][t] = (in ? (sbase + yy * S + xx) : K::NP) * K::ROWB + h * 16;
             }
         }
     }
@@ -204,7 +214,8 @@ typedef ConvCfg<128, 16, 256, 2, 2, HD_CONV_DEPTH> ConvL0;    // one face per wo
 typedef ConvCfg<256, 8, 128, 2, 4, HD_CONV_DEPTH> ConvL1;     // two faces: 2 row groups x 4 K-quarters
 typedef ConvCfg<512, 4, 64, 2, 8, HD_CONV_DEPTH> ConvL2;      // four faces: 1 row group x 8 K-slices
 typedef ConvCfg<1024, 2, 32, 1, 8, 16> ConvL3; // eight faces; 590 KB of weights per workgroup: deeper ring
-// latent 32: faces of side 32 >> l (level 0's 32x32 faces do not fit LDS and keep the gather form)
+// latent 32: faces of side 32 >> l; level 0's 32x32 faces do not fit LDS: strips of 8 image rows + halo (87 KB)
+typedef ConvCfg<128, 32, 256, 2, 2, HD_CONV_DEPTH, true> ConvL0x32;
 typedef ConvCfg<256, 16, 256, 2, 2> ConvL1x32;
 typedef ConvCfg<512, 8, 64, 2, 8> ConvL2x32;
 typedef ConvCfg<1024, 4, 32, 1, 8, 16> ConvL3x32;

@@ -772,7 +772,7 @@ void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Hc
         int which = -1;
         if (C == 128 && H == 16) which = 0; else if (C == 256 && H == 8) which = 1; else if (C == 512 && H == 4) which = 2;
         else if (C == 1024 && H == 2) which = 3; else if (C == 256 && H == 16) which = 4; else if (C == 512 && H == 8) which = 5;
-        else if (C == 1024 && H == 4) which = 6; else if (C == 2048 && H == 2) which = 7;
+        else if (C == 1024 && H == 4) which = 6; else if (C == 2048 && H == 2) which = 7; else if (C == 128 && H == 32) which = 8;
         if (which >= 0) {
             Op op;
             op.name = name; op.out = out; op.out_elems = (size_t)M * C;
@@ -785,6 +785,7 @@ void add_hca(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Hc
                     case 4: return launch_hca_conv<ConvL1x32>(q, s);
                     case 5: return launch_hca_conv<ConvL2x32>(q, s);
                     case 6: return launch_hca_conv<ConvL3x32>(q, s);
+                    case 8: return launch_hca_conv<ConvL0x32>(q, s);
                     default: return launch_hca_conv<ConvL4x32>(q, s);
                 }
             };

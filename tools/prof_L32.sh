@@ -1,5 +1,5 @@
 set -e
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r02_L32; mkdir -p $OUT; export TMPDIR=/tmp
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/${1:-r03}_L32; mkdir -p $OUT; export TMPDIR=/tmp
 cd /tmp
 HD_DUMP_OPS=$OUT/ops.txt timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" --steps 1 --warmup 0 --latent 32 --kind ddim --diffusion-steps 30 --no-cpu-baseline > "$OUT/trace.log" 2>&1
 cd $ROOT
