@@ -102,13 +102,26 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
             sl = str(l)
             film = O.film_vectors(P, p, temb)
             M = B * H * H
-            if kind == "conv2_gate_pool":
+            def gate_of_x():
+                # conv1 -> depthwise 3x3 -> SimpleGate on the HIP path's own block input (X is not written before conv5)
                 inp = _nchw(_read(L, ctx, "X" + sl), B, C, H)
-                run_to(i + 1)
                 h = O.layernorm2d(inp, P[p + ".norm1.weight"], P[p + ".norm1.bias"], prec=PR) * (film[1] + 1) + film[0]
                 t1 = O._gemm_conv(h, P[p + ".conv1.weight"], P[p + ".conv1.bias"], PR)
-                g = O.simple_gate(F.conv2d(t1, P[p + ".conv2.weight"], P[p + ".conv2.bias"], padding=1, groups=2 * C))
+                return O.simple_gate(F.conv2d(t1, P[p + ".conv2.weight"], P[p + ".conv2.bias"], padding=1, groups=2 * C))
+            if kind == "conv1":
+                # unfused form (faces too large for the fused depthwise epilogue: latent 32, level 0): T1 has no tap of its own, the
+                # next launch's G is checked against the oracle's conv1 -> depthwise -> gate of the same input
+                report.append(f"{i:3d} {name:42s} (checked through the next launch's G)")
+            elif kind == "conv2_gate_pool":
+                unfused = names[i - 1].endswith(".conv1")
+                g = gate_of_x()
+                run_to(i + 1)
                 check(i, name, "G", _read(L, ctx, "G" + sl)[:M * C], _rows(PR.q(g)), True)
+                if not unfused:                                       # unfused: band sums only, the mean is pool_finish's output
+                    check(i, name, "pooled", _read(L, ctx, "pooled" + sl)[:B * C], g.mean(dim=(2, 3)).reshape(-1), False)
+            elif kind == "pool_finish":
+                g = gate_of_x()
+                run_to(i + 1)
                 check(i, name, "pooled", _read(L, ctx, "pooled" + sl)[:B * C], g.mean(dim=(2, 3)).reshape(-1), False)
             elif kind == "sca":
                 pooled = _read(L, ctx, "pooled" + sl)[:B * C].reshape(B, C, 1, 1)
@@ -133,7 +146,7 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
                 g2 = O.simple_gate(O._gemm_conv(h, P[p + ".conv4.weight"], P[p + ".conv4.bias"], PR))
                 check(i, name, "G2", _read(L, ctx, "G" + sl)[:M * C], _rows(PR.q(g2)), True)
             elif kind == "conv5":
-                fused = names[i - 1].endswith(".conv2_gate_pool")      # levels 0/1: sca .. conv5 in one launch (hd_chain.hpp)
+                fused = names[i - 1].endswith((".conv2_gate_pool", ".pool_finish"))      # levels 0/1: sca .. conv5 in one launch (hd_chain.hpp)
                 g = _nchw(_read(L, ctx, "G" + sl), B, C, H)
                 if fused:
                     inp = _nchw(_read(L, ctx, "X" + sl), B, C, H)
