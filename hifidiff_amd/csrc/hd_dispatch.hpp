@@ -10,8 +10,13 @@ enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE,
 
 // mode: 0 = tall T128, 1 = tall T64, 2 = skinny 64 rows, 3 = skinny 32 rows, 4 = tall T32W (32 rows x 256 cols),
 //       5 / 6 = skinny with 4 / 8 M-split waves (128 / 256 rows per workgroup; long-K gathers at large M)
+//       + 16: the deep-prefetch tall kernel where the loader / epilogue pair has it and the shape fits (latent 32: levels 2 / 3)
 template <class LD, class EP, bool PAIR>
 hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
+    if constexpr (ld_is_deep<LD>::value && ep_is_deep<EP>::value) {
+        if ((mode & 16) && deep_shape_ok<PAIR>(p)) return launch_gemm_deep<LD, EP, PAIR>(p, s);
+    }
+    mode &= 15;
     if constexpr (PAIR) {
         switch (mode) {
             case 0: return launch_gemm<T128P, LD, EP>(p, s);

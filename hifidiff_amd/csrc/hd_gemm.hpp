@@ -231,6 +231,7 @@ template <bool PER_FACE>
 struct LdF32LN_T {
     static constexpr int kRawRegs = 4;
     static constexpr bool kGainBiasLds = !PER_FACE, kSplit = false, kStaticK = true;
+    static constexpr bool kDeep = !PER_FACE;                           // gemm_deep_kernel: the shared-FiLM form only
     struct St { const unsigned short* rowp; const float* gain; const float* bias; const float* gbl; float mu, rstd; bool valid; };   // mu holds -mean*rstd
     struct Raw { uint4 x; };
     // block prologue in two halves so that its (small) loads can be issued before the weight / A streams and
@@ -471,6 +472,7 @@ typedef LdF32LN_T<true> LdF32LNFace;       // per-face timesteps
 struct LdBF16Plain {
     static constexpr int kRawRegs = 4;
     static constexpr bool kGainBiasLds = false, kSplit = false, kStaticK = true;
+    static constexpr bool kDeep = true;
     struct St { const unsigned short* rowp; bool valid; };
     struct Raw { uint4 x; };
     struct Pre {};
@@ -661,6 +663,7 @@ struct EpScaBF16 {
 // out(fp32) = resid + rscale[col] * (acc + bias)      (y = inp + x*beta, out = y + x*gamma)
 struct EpResidF32 {
     static constexpr bool kStats = true, kTile = false;
+    static constexpr bool kDeep = true;
     static __device__ __forceinline__ size_t stat_index(const GemmP& p, int row, int tile_idx) { return (size_t)row * (p.N >> 5) + tile_idx; }
     static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = 0.f; c.rscale = p.rscale[col]; return c; }
     static __device__ __forceinline__ float pre(const GemmP& p, int row, int col) {
@@ -681,6 +684,7 @@ struct EpResidF32 {
 // PAIR: out(bf16)[row][col] = (acc1 + bias[col]) * (acc2 + bias[col + N/2])   (conv4 -> SimpleGate)
 struct EpGateBF16 {
     static constexpr bool kStats = false, kTile = false;
+    static constexpr bool kDeep = true;
     static __device__ __forceinline__ ColC col_init(const GemmP& p, int col) { ColC c; c.bias = p.bias[col]; c.bias2 = p.bias[col + (p.N >> 1)]; c.rscale = 1.f; return c; }
     static __device__ __forceinline__ float pre(const GemmP&, int, int) { return 0.f; }
     static __device__ __forceinline__ void store2(const GemmP& p, int row, int col, float v1, float v2, const ColC& c) {
@@ -971,6 +975,235 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(const GemmP p) {
         }
     }
     HD_STAMP(5);
+}
+
+
+// ------------------------------------------------------------------------------------- tall kernel, deep prefetch
+// The tall kernel above keeps ONE chunk in flight and drains it at every chunk's __syncthreads(): with K = 512 .. 1024 that is
+// 8 .. 16 exposed memory round trips, which is why the skinny kernel (whole K slice of a wave in flight) was used for every long-K
+// GEMM.  At latent 32 the LayerNorm / plain GEMMs of levels 2 and 3 have M = 1024 .. 4096 rows: 64-row skinny tiles put
+// (64 + 64) rows of operands through every workgroup and two workgroups on a CU.  This form is the tall kernel's tiling
+// (128 rows x 32 (gate) columns, A through LDS, one row tile per wave: (128 + 32 or 64) operand rows per CU) with a straight-line
+// K loop: NCH = K / 64 is a template parameter, loads are unconditional (host checks: K % 64 == 0, whole column tiles; rows
+// beyond M re-read row 0 and are never stored) and P chunks ahead (register rings of raw A units and of this wave's quarter of
+// the chunk's B fragments: each 1 KiB fragment is requested by ONE wave and shared through LDS -- with every wave loading its own
+// copy the four-fold B requests made the pair GEMM slower than the skinny kernel, 19.4 against 17.6 us), the chunk barrier is
+// LDS-only (no vector-memory drain), so the compiler's counted waits leave P chunks in flight.
+template <class LD, class = void> struct ld_is_deep { static constexpr bool value = false; };
+template <class LD> struct ld_is_deep<LD, decltype((void)LD::kDeep)> { static constexpr bool value = LD::kDeep; };
+template <class EP, class = void> struct ep_is_deep { static constexpr bool value = false; };
+template <class EP> struct ep_is_deep<EP, decltype((void)EP::kDeep)> { static constexpr bool value = EP::kDeep; };
+
+template <class C, class LD, class EP, int NCH, int P>
+__global__ __launch_bounds__(C::THREADS) void gemm_deep_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(C::WN == 1 && C::TN == 1 && C::WM == 4 && NCH >= P + 1, "one 32-column (pair) tile per workgroup, four row tiles");
+    constexpr int NF = C::TNT * 4;                         // 1 KiB B fragments per chunk: (gate half, k-step)
+    constexpr int FPW = NF / 4;                            // ... requested per wave: every fragment crosses the CU's load path once,
+    constexpr int B_BUF = NF * 1024;                       // the four waves share it through LDS
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w_m = wave;
+    const int ksteps_total = p.Kp >> 4;
+    // block -> (row group, column tile): the row groups that stream one weight tile get linear ids that are equal mod 8 (one
+    // XCD, one L2 fill per weight tile) when the weights outweigh the activations (gemm_skinny_kernel's map)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_tile_affine && (gridDim.y & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, j = lin >> 3;
+        bx = j % (int)gridDim.x;
+        by = (j / (int)gridDim.x) * 8 + (lin & 7);
+    }
+    const int row0 = bx * C::BM;
+    const int tile0 = by, tile1 = by + (p.N >> 6);         // pair: the second gate half starts at N/2 = 32 * (N/64)
+
+    float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + C::GB_OFF) : nullptr;
+    char* sB = smem + C::GB_OFF + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0);
+    typename LD::St st[C::UNITS];
+    int u_ldsoff[C::UNITS];
+    const int kq = tid & 7;
+#pragma unroll
+    for (int u = 0; u < C::UNITS; ++u) {
+        const int rl = (tid >> 3) + u * (C::THREADS / 8);
+        u_ldsoff[u] = rl * LDS_ROW;
+        LD::unit_init(p, st[u], row0 + rl, rl, smem + C::STATS_OFF, gb);
+    }
+    f32x16_t acc[C::TNT];
+#pragma unroll
+    for (int tn = 0; tn < C::TNT; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+
+    typename LD::Raw raw[P][C::UNITS];
+    typedef unsigned dq_u32x4 __attribute__((ext_vector_type(4)));
+    dq_u32x4 braw0[P], braw1[P];
+    // this wave's fragments of a chunk: f = wave * FPW + i -> (gate half f / 4, k-step f % 4)
+    const int f0 = wave * FPW, f1 = wave * FPW + (FPW - 1);
+    const uint4* Wf0 = p.W + ((size_t)((f0 >> 2) ? tile1 : tile0) * ksteps_total + (f0 & 3)) * 64 + lane;
+    const uint4* Wf1 = p.W + ((size_t)((f1 >> 2) ? tile1 : tile0) * ksteps_total + (f1 & 3)) * 64 + lane;
+    char* sBw = sB + (wave * FPW) * 1024 + lane * 16;      // where this wave's fragments go
+#define HD_DEEP_LOAD(chunk)                                                                               \
+    {                                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < C::UNITS; ++u) LD::fetch_nc(p, st[u], (chunk) * BK, kq, raw[(chunk) % P][u]); \
+        braw0[(chunk) % P] = *reinterpret_cast<const dq_u32x4*>(Wf0 + (size_t)(chunk) * 4 * 64);           \
+        if (FPW == 2) braw1[(chunk) % P] = *reinterpret_cast<const dq_u32x4*>(Wf1 + (size_t)(chunk) * 4 * 64); \
+    }
+#define HD_DEEP_WRITE(chunk)                                                                              \
+    {                                                                                                      \
+        typename LD::ChunkC cc;                                                                            \
+        LD::chunk_consts(p, st[0], (chunk) * BK, kq, cc);                                                  \
+        _Pragma("unroll") for (int u = 0; u < C::UNITS; ++u)                                               \
+            lds_write_unit<LD::kSplit>(smem + ((chunk) & 1) * C::A_BUF + u_ldsoff[u], kq,                  \
+                                       LD::finish_nc(p, st[u], (chunk) * BK, kq, raw[(chunk) % P][u], cc)); \
+        *reinterpret_cast<dq_u32x4*>(sBw + ((chunk) & 1) * B_BUF) = braw0[(chunk) % P];                    \
+        if (FPW == 2) *reinterpret_cast<dq_u32x4*>(sBw + ((chunk) & 1) * B_BUF + 1024) = braw1[(chunk) % P]; \
+    }
+#pragma unroll
+    for (int d = 0; d < P; ++d) HD_DEEP_LOAD(d);
+    // LayerNorm statistics / FiLM row: do not depend on the loads above (its workgroup barrier drains them once)
+    LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
+#pragma unroll
+    for (int u = 0; u < C::UNITS; ++u) LD::unit_stats(st[u], (tid >> 3) + u * (C::THREADS / 8), smem + C::STATS_OFF);
+    HD_DEEP_WRITE(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int a_lane_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + P < NCH) {
+            HD_DEEP_LOAD(c + P);
+            // keep the requests HERE: left to itself the scheduler sinks them to just before their use P chunks later (shorter
+            // live ranges), i.e. issues them and waits for them at once
+            asm volatile("" ::: "memory");
+        }
+        const char* sA = smem + (c & 1) * C::A_BUF + a_lane_off + (w_m * 32) * LDS_ROW;
+        const char* sBc = sB + (c & 1) * B_BUF + lane * 16;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(sA + s4 * 32);
+#pragma unroll
+            for (int tn = 0; tn < C::TNT; ++tn) {
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(sBc + (tn * 4 + s4) * 1024);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tn], 0, 0, 0);
+            }
+        }
+        if (c + 1 < NCH) HD_DEEP_WRITE(c + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#undef HD_DEEP_LOAD
+#undef HD_DEEP_WRITE
+
+    const int ncols = C::PAIR ? (p.N >> 1) : p.N;
+    const int rtile = row0 + w_m * 32;
+    const int rbase = rtile + 4 * (lane >> 5);
+    const int col = tile0 * 32 + (lane & 31);
+    if (rtile + 32 <= p.M) tile_epilogue_mfma<true, C::PAIR, EP>(p, acc[0], acc[C::PAIR ? 1 : 0], rbase, col, ncols, tile0, lane);
+    else tile_epilogue_mfma<false, C::PAIR, EP>(p, acc[0], acc[C::PAIR ? 1 : 0], rbase, col, ncols, tile0, lane);
+}
+
+// The same for a PAIR GEMM (LayerNorm -> conv4 -> SimpleGate) with EIGHT waves: four row tiles x the two gate halves.  A wave
+// owns one half (one accumulator, four MFMAs per chunk instead of eight behind each other), requests ONE of the chunk's eight B
+// fragments, and the LayerNorm transform of the A chunk is spread over 512 threads; the second half's accumulators meet the first
+// half's through LDS once, in the epilogue.  (With four waves a 128-row workgroup is one wave per SIMD and the chunk chain --
+// LDS reads, eight dependent MFMAs, transform, LDS writes, barrier -- has nothing to overlap with: 18.3 us against 17.6 us for
+// the skinny kernel at M = 1024.)
+template <class LD, class EP, int NCH, int P>
+__global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 128, THREADS = 512, UNITS = BM * 8 / THREADS;           // 2 (row, 8 k) staging units per thread
+    constexpr int A_BUF = BM * LDS_ROW, STATS_OFF = 2 * A_BUF, GB_OFF = STATS_OFF + BM * 8, B_BUF = 8 * 1024;
+    static_assert(NCH >= P + 1 && 4 * 16 * 64 * 4 <= 2 * A_BUF, "prefetch depth; the epilogue exchange fits the dead A buffers");
+    typedef unsigned dq_u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w_m = wave & 3, half = wave >> 2;
+    const int ksteps_total = p.Kp >> 4;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_tile_affine && (gridDim.y & 7) == 0) {                   // gemm_deep_kernel's block map
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, j = lin >> 3;
+        bx = j % (int)gridDim.x;
+        by = (j / (int)gridDim.x) * 8 + (lin & 7);
+    }
+    const int row0 = bx * BM;
+    const int tile0 = by, tile1 = by + (p.N >> 6);
+
+    float* gb = LD::kGainBiasLds ? reinterpret_cast<float*>(smem + GB_OFF) : nullptr;
+    char* sB = smem + GB_OFF + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0);
+    typename LD::St st[UNITS];
+    int u_ldsoff[UNITS];
+    const int kq = tid & 7;
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int rl = (tid >> 3) + u * (THREADS / 8);
+        u_ldsoff[u] = rl * LDS_ROW;
+        LD::unit_init(p, st[u], row0 + rl, rl, smem + STATS_OFF, gb);
+    }
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    typename LD::Raw raw[P][UNITS];
+    dq_u32x4 braw[P];
+    // this wave's B fragment of a chunk: f = wave -> (gate half wave / 4, k-step wave % 4)
+    const uint4* Wf = p.W + ((size_t)(half ? tile1 : tile0) * ksteps_total + (wave & 3)) * 64 + lane;
+    char* sBw = sB + wave * 1024 + lane * 16;
+#define HD_DEEP_LOAD(chunk)                                                                               \
+    {                                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < UNITS; ++u) LD::fetch_nc(p, st[u], (chunk) * BK, kq, raw[(chunk) % P][u]); \
+        braw[(chunk) % P] = *reinterpret_cast<const dq_u32x4*>(Wf + (size_t)(chunk) * 4 * 64);            \
+    }
+#define HD_DEEP_WRITE(chunk)                                                                              \
+    {                                                                                                      \
+        typename LD::ChunkC cc;                                                                            \
+        LD::chunk_consts(p, st[0], (chunk) * BK, kq, cc);                                                  \
+        _Pragma("unroll") for (int u = 0; u < UNITS; ++u)                                                  \
+            lds_write_unit<LD::kSplit>(smem + ((chunk) & 1) * A_BUF + u_ldsoff[u], kq,                     \
+                                       LD::finish_nc(p, st[u], (chunk) * BK, kq, raw[(chunk) % P][u], cc)); \
+        *reinterpret_cast<dq_u32x4*>(sBw + ((chunk) & 1) * B_BUF) = braw[(chunk) % P];                     \
+    }
+#pragma unroll
+    for (int d = 0; d < P; ++d) HD_DEEP_LOAD(d);
+    LD::template block_init<BM, THREADS>(p, row0, smem + STATS_OFF, gb, tid);
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) LD::unit_stats(st[u], (tid >> 3) + u * (THREADS / 8), smem + STATS_OFF);
+    HD_DEEP_WRITE(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int a_lane_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + P < NCH) {
+            HD_DEEP_LOAD(c + P);
+            asm volatile("" ::: "memory");                              // keep the requests here (see gemm_deep_kernel)
+        }
+        const char* sA = smem + (c & 1) * A_BUF + a_lane_off + (w_m * 32) * LDS_ROW;
+        const char* sBc = sB + (c & 1) * B_BUF + (half * 4) * 1024 + lane * 16;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(sA + s4 * 32);
+            const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(sBc + s4 * 1024);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        if (c + 1 < NCH) HD_DEEP_WRITE(c + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#undef HD_DEEP_LOAD
+#undef HD_DEEP_WRITE
+    // second gate half -> LDS (the A buffers are dead: the loop ended with a barrier), first half runs the pair epilogue
+    float* xch = reinterpret_cast<float*>(smem);
+    if (half) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xch[(w_m * 16 + i) * 64 + lane] = acc[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!half) {
+        f32x16_t acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[i] = xch[(w_m * 16 + i) * 64 + lane];
+        const int ncols = p.N >> 1;
+        const int rtile = row0 + w_m * 32;
+        const int rbase = rtile + 4 * (lane >> 5);
+        const int col = tile0 * 32 + (lane & 31);
+        if (rtile + 32 <= p.M) tile_epilogue_mfma<true, true, EP>(p, acc, acc2, rbase, col, ncols, tile0, lane);
+        else tile_epilogue_mfma<false, true, EP>(p, acc, acc2, rbase, col, ncols, tile0, lane);
+    }
 }
 
 template <class EP, class = void> struct ep_is_sca_tile { static constexpr bool value = false; };
@@ -1466,6 +1699,33 @@ inline hipError_t launch_gemm(const GemmP& p, hipStream_t s) {
     }
     dim3 grid((p.M + C::BM - 1) / C::BM, (ncols + C::NCOLS - 1) / C::NCOLS, 1);
     hipLaunchKernelGGL((gemm_kernel<C, LD, EP>), grid, dim3(C::THREADS), smem, s, p);
+    return hipGetLastError();
+}
+
+// deep-prefetch tall kernel: 128-row tiles, 32 (gate) columns, K = 512 or 1024 (see gemm_deep_kernel); false when the shape is
+// not one of its own (the caller then uses the mode it would have used otherwise)
+template <bool PAIR>
+inline bool deep_shape_ok(const GemmP& p) {
+    const int ncols = PAIR ? p.N / 2 : p.N;
+    // measured at latent 32 (profiles/r03_latent32_kernel_table.txt): pair GEMM 16.5 us against 17.6 us for the skinny kernel at
+    // M = 1024 and 16.4 against 19.7 at M = 4096; plain GEMM 12.5 against 14.7 at M = 4096 but 13.8 against 13.0 at M = 1024
+    return p.K == p.Kp && (p.Kp == 512 || p.Kp == 1024) && p.M >= (PAIR ? 1024 : 2048) && ncols % 32 == 0 && p.film_face_stride == 0 &&
+           ((p.M + 127) / 128) * (ncols / 32) >= 256;
+}
+template <class LD, class EP, bool PAIR>
+inline hipError_t launch_gemm_deep(const GemmP& p, hipStream_t s) {
+    typedef Cfg<4, 1, 1, 1, PAIR> C;
+    constexpr int P = 4;                                  // chunks in flight per wave (A units + this wave's share of the B fragments)
+    const int ncols = PAIR ? p.N / 2 : p.N;
+    const int smem = C::SMEM + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0) + 2 * (PAIR ? 8 : 4) * 1024;     // + two B chunk buffers
+    dim3 grid((p.M + C::BM - 1) / C::BM, ncols / 32, 1);
+    if constexpr (PAIR) {                                  // eight waves: four row tiles x the two gate halves
+        if (p.Kp == 1024) hipLaunchKernelGGL((gemm_deep_pair8_kernel<LD, EP, 16, P>), grid, dim3(512), smem, s, p);
+        else hipLaunchKernelGGL((gemm_deep_pair8_kernel<LD, EP, 8, P>), grid, dim3(512), smem, s, p);
+        return hipGetLastError();
+    }
+    if (p.Kp == 1024) hipLaunchKernelGGL((gemm_deep_kernel<C, LD, EP, 16, P>), grid, dim3(C::THREADS), smem, s, p);
+    else hipLaunchKernelGGL((gemm_deep_kernel<C, LD, EP, 8, P>), grid, dim3(C::THREADS), smem, s, p);
     return hipGetLastError();
 }
 

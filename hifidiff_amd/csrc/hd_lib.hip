@@ -575,6 +575,12 @@ GemmP base_gemm(const PackedW& w, int M) {
 
 void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p, LdKind lk, EpKind ek) {
     int t128 = choose_mode(p, ek == EK_GATE || ek == EK_DWGATE);   // (kernel mode; name kept for the capture list)
+    {   // many rows, long K, LayerNorm -> gate or bf16 -> residual (latent 32, levels 2 / 3): the deep-prefetch tall kernel; the
+        // launch falls back to the mode above when the run-time shape does not fit (per-face timesteps)
+        static const bool no_deep = hd_env("HD_NO_DEEP") != nullptr;
+        const bool kinds = (lk == LK_LN && ek == EK_GATE) || (lk == LK_BF16 && ek == EK_RESID);
+        if (kinds && !no_deep && (ek == EK_GATE ? deep_shape_ok<true>(p) : deep_shape_ok<false>(p))) t128 |= 16;
+    }
     {   // each XCD re-fetches what its workgroups read: share the bigger operand through the XCD's L2
         const size_t a_bytes = (size_t)p.M * p.Kp * ((lk == LK_BF16 || lk == LK_BF16S || lk == LK_CONV_BF16 || lk == LK_LN) ? 2 : 4);
         p.xcd_tile_affine = ((size_t)p.N * p.Kp * 2 > a_bytes) ? 1 : 0;
@@ -589,7 +595,7 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
     Chain* chp = c->ch;
     auto gp = std::make_shared<GemmP>(p);
     op.gemm = gp;
-    op.skinny_affine = p.xcd_tile_affine && t128 != 0 && t128 != 1 && t128 != 4;     // modes 0/1/4 are the tall kernel
+    op.skinny_affine = p.xcd_tile_affine && (t128 & 16) == 0 && t128 != 0 && t128 != 1 && t128 != 4;     // modes 0/1/4 are the tall kernel
     op.run = [c, chp, gp, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
                         if (film && gp->film == nullptr) {        // denoiser FiLM rows live in the (re-allocatable) table
                             GemmP q = *gp;
