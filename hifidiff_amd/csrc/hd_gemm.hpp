@@ -384,7 +384,9 @@ struct LdF32LN_T {
         // op_sel, out of the pair the LDS read delivered.  Checks of the hardware rules this could have broken all came back
         // clean (tools/vmorder_bench, ldswar_bench, mfma_overlap_bench, pkfma_bench).
         // tests/test_gpu_parity.py::test_every_launch_is_reproducible guards it.
+#ifndef HD_UNIT_STATS_PLAIN                                         // tools/det_bench builds the form without it for the ISA pair under profiles/
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(s.x), "+v"(s.y));
+#endif
         st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
     }
     static __device__ __forceinline__ void fetch(const GemmP& p, const St& st, int kc, int kq, Raw& r) {
