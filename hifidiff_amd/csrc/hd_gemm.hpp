@@ -384,8 +384,12 @@ struct LdF32LN_T {
         // op_sel, out of the pair the LDS read delivered.  Checks of the hardware rules this could have broken all came back
         // clean (tools/vmorder_bench, ldswar_bench, mfma_overlap_bench, pkfma_bench).
         // tests/test_gpu_parity.py::test_every_launch_is_reproducible guards it.
-#ifndef HD_UNIT_STATS_PLAIN                                         // tools/det_bench builds the form without it for the ISA pair under profiles/
+#if !defined(HD_UNIT_STATS_PLAIN)                                   // tools/det_bench builds the other forms for profiles/r03_unit_stats_isa
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(s.x), "+v"(s.y));
+#elif HD_UNIT_STATS_PLAIN == 2                                      // opaque values only: no wait, no idle cycles
+        asm volatile("" : "+v"(s.x), "+v"(s.y));
+#elif HD_UNIT_STATS_PLAIN == 3                                      // wait + idle cycles, values NOT opaque
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" ::: "memory");
 #endif
         st.mu = -s.x * s.y; st.rstd = s.y;                            // x_hat = fma(x, rstd, -mean*rstd)
     }
