@@ -383,6 +383,9 @@ struct LdF32LN_T {
         // the two values opaque, so they are consumed here and kept in registers of their own instead of being read, with
         // op_sel, out of the pair the LDS read delivered.  Checks of the hardware rules this could have broken all came back
         // clean (tools/vmorder_bench, ldswar_bench, mfma_overlap_bench, pkfma_bench).
+        // r03 (profiles/r03_unit_stats_isa, tools/det_bench with -DHD_UNIT_STATS_PLAIN=n): opaque values WITHOUT the wait are clean in
+        // 299 launches, the wait + idle cycles WITHOUT opacity still differ in 59-93 of 299; the listings differ in one operand:
+        // v_pk_fma_f32 ... op_sel:[0,1,0] op_sel_hi:[1,1,0] taking rstd from the high register of the ds_read_b64 pair.
         // tests/test_gpu_parity.py::test_every_launch_is_reproducible guards it.
 #if !defined(HD_UNIT_STATS_PLAIN)                                   // tools/det_bench builds the other forms for profiles/r03_unit_stats_isa
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(s.x), "+v"(s.y));
