@@ -840,12 +840,15 @@ def test_latent32_at_batch_against_oracle_and_full_ddim250(gpu):
     # every launch of the latent-32 program against the oracle's arithmetic on the launch's own inputs (tools/op_forced.py): the
     # unfused conv1 -> depthwise -> pool_finish sequence of level 0 and the strip-staged HCA conv on 32 x 32 faces are only here.
     # Measured r03 (profiles/r03_op_forced_L32_B2.txt): fp32 outputs 5.0e-5, bf16-stored outputs 4.9e-4.
+    # At batch 64 the scan runs the configuration's own instantiations: the deep-prefetch 128-row GEMMs of levels 2 / 3, 64-row tiles
+    # elsewhere (profiles/r03_op_forced_L32_B64.txt: 2.5e-5 / 2.0e-4).
     import op_forced
-    rep = []
-    worst = op_forced.forced_scan(m, w32, x[:2], crl[:2], crf[:2], 500.0, rep)
-    assert len(rep) >= 200 and not [r for r in rep if "no rule" in r], [r for r in rep if "no rule" in r][:3]
-    assert not [r for r in rep if "<<<<<<" in r], [r for r in rep if "<<<<<<" in r][:8]
-    assert worst["fp32"] <= 3e-4 and worst["bf16"] <= 3e-3, worst
+    for nb in (2, 64):
+        rep = []
+        worst = op_forced.forced_scan(m, w32, x[:nb], crl[:nb], crf[:nb], 500.0, rep)
+        assert len(rep) >= 200 and not [r for r in rep if "no rule" in r], [r for r in rep if "no rule" in r][:3]
+        assert not [r for r in rep if "<<<<<<" in r], [r for r in rep if "<<<<<<" in r][:8]
+        assert worst["fp32"] <= 3e-4 and worst["bf16"] <= 3e-3, (nb, worst)
 
 
 def test_layernorm_gemm_launches_are_reproducible_over_300_runs(gpu, weights16, model2_launches):
