@@ -301,6 +301,7 @@ def main():
         out = one_pass(k + rank * 7919)
     fence()
     dt = time.perf_counter() - t0
+    model.check(synchronize=False)                         # a persistent stage that gave up (results NaN) fails the run here
     # HIP-event time of the last pass's replay loop
     loop_ms, step_ms_avg = ctypes.c_double(), ctypes.c_double()
     wbytes, fl = ctypes.c_int64(), ctypes.c_double()

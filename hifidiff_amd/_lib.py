@@ -24,7 +24,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
 EXPORTS = [
     "hd_create", "hd_create_unconditional", "hd_prepare_unconditional", "hd_cr_create", "hd_cr_forward", "hd_vae_create", "hd_vae_encode", "hd_vae_decode", "hd_destroy", "hd_last_error", "hd_load_weights", "hd_finalize_weights", "hd_prepare",
     "hd_prepare_from_priors", "hd_fpg", "hd_idc", "hd_eps", "hd_sample", "hd_scheduler_step", "hd_num_ops", "hd_num_chains",
-    "hd_debug_limit_ops", "hd_debug_op_name", "hd_debug_read_op", "hd_debug_read", "hd_debug_write", "hd_set_option", "hd_get_option",
+    "hd_debug_limit_ops", "hd_debug_op_name", "hd_debug_read_op", "hd_debug_read", "hd_debug_write", "hd_set_option", "hd_get_option", "hd_check",
     "hd_set_profiling", "hd_get_profile",
 ]
 
@@ -104,6 +104,7 @@ def lib():
     L.hd_debug_write.argtypes = [vp, ctypes.c_char_p, vp, i64]
     L.hd_set_option.argtypes = [vp, ctypes.c_char_p, i32]
     L.hd_get_option.argtypes = [vp, ctypes.c_char_p]
+    L.hd_check.argtypes = [vp]
     L.hd_set_profiling.argtypes = [vp, i32]
     L.hd_get_profile.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]

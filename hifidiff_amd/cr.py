@@ -87,6 +87,8 @@ class CoarseRestoration(nn.Module):
                 d.shape[j] = s
         if self._loaded:                     # re-load: weights are packed once per context
             L.hd_destroy(self._ctx)
+            self._ctx = None
+            self._loaded, self._batch = False, None          # nothing usable until finalize has succeeded
             self._ctx = self._create(self._device.index)
         with torch.cuda.device(self._device):
             _lib.check(L.hd_load_weights(self._ctx, descs, len(man)), self._ctx)

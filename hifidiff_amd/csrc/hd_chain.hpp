@@ -321,12 +321,8 @@ template <int C, int MT>
 inline hipError_t launch_chain(const ChainP& p, hipStream_t s) {
     typedef ChainCfg<C, MT> K;
     if (K::SMEM > 65536) {
-        static bool granted = false;
-        if (!granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&naf_chain_kernel<C, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
-            if (e != hipSuccess) return e;
-            granted = true;
-        }
+        static std::atomic<unsigned long long> granted{0};
+        { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&naf_chain_kernel<C, MT>), K::SMEM, granted); if (e != hipSuccess) return e; }
     }
     hipLaunchKernelGGL((naf_chain_kernel<C, MT>), dim3((p.M + K::BM - 1) / K::BM), dim3(K::THREADS), K::SMEM, s, p);
     return hipGetLastError();

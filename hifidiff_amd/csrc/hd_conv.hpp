@@ -198,12 +198,8 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
 template <class K>
 inline hipError_t launch_hca_conv(const ConvP& p, hipStream_t s) {
     if (K::SMEM > 65536) {
-        static bool granted = false;
-        if (!granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hca_conv_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
-            if (e != hipSuccess) return e;
-            granted = true;
-        }
+        static std::atomic<unsigned long long> granted{0};
+        { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&hca_conv_kernel<K>), K::SMEM, granted); if (e != hipSuccess) return e; }
     }
     hipLaunchKernelGGL((hca_conv_kernel<K>), dim3((p.M + K::BM - 1) / K::BM, K::C / 32), dim3(K::THREADS), K::SMEM, s, p);
     return hipGetLastError();

@@ -35,7 +35,9 @@ struct FStageP {
     float* pool_part;                      // [faces][CL][C] channel sums of the gate of each workgroup's rows
     const float* film; float ln_eps;
     unsigned *flags, *gstate;              // [64 faces][16] words each
-    unsigned* tmo;
+    unsigned* tmo;                         // host-visible timeout word (pinned, device-mapped)
+    unsigned* abort_dev;                   // the same code in device memory, read at entry by every stage launch (hd_xcd.hpp)
+    int test_abort;                        // fault injection: 1000 + b = face 0 gives up its pool wait of block b
     int block_limit;                       // introspection: stop after this many blocks (<= 0: all)
 #ifdef HD_STAMPS
     unsigned long long* stamps;            // [block][workgroup][8]
@@ -104,7 +106,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
         unsigned* dst = reinterpret_cast<unsigned*>(s_blk);
         for (int i = tid; i < p.nblocks * (int)(sizeof(XBlockW) / 4); i += K::THREADS) dst[i] = src[i];
         if (tid == 0) {
-            s_abort = 0u;
+            s_abort = __hip_atomic_load((fs_gu32*)p.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // an earlier stage of this call gave up
             s_base = __hip_atomic_load((fs_gu32*)(p.gstate + face * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 64u;
         }
     }
@@ -133,7 +135,11 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
                 const unsigned v = lane < K::CL ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : value;
                 if (__all((int)(v - value) >= 0)) break;
                 if (spins > XS_SPINS) {
-                    if (lane == 0) { s_abort = 1u; __hip_atomic_store((fs_gu32*)p.tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                    if (lane == 0) {
+                        s_abort = 1u;
+                        __hip_atomic_store((fs_gu32*)p.abort_dev, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((fs_gu32*)p.tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -144,9 +150,14 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
         if (wave == 0) {
             for (unsigned spins = 0;; ++spins) {
                 const unsigned v = lane < K::CL ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : value;
-                if (__all((int)(v - value) >= 0)) break;
-                if (spins > XS_SPINS) {
-                    if (lane == 0) { s_abort = 1u; __hip_atomic_store((fs_gu32*)p.tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                const bool inject = p.test_abort >= 1000 && (int)(code & 0xffu) == p.test_abort - 1000 && face == 0;
+                if (!inject && __all((int)(v - value) >= 0)) break;
+                if (spins > XS_SPINS || inject) {
+                    if (lane == 0) {
+                        s_abort = 1u;
+                        __hip_atomic_store((fs_gu32*)p.abort_dev, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((fs_gu32*)p.tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -458,12 +469,8 @@ template <int C>
 inline hipError_t launch_face_stage(const FStageP& p, hipStream_t s) {
     typedef FaceCfg<C> K;
     if (p.B < 1 || p.B > 64 || p.nblocks < 1 || p.nblocks > XS_MAXBLK) return hipErrorInvalidValue;
-    static bool granted = false;
-    if (!granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&naf_face_stage_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
-        if (e != hipSuccess) return e;
-        granted = true;
-    }
+    static std::atomic<unsigned long long> granted{0};
+        { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&naf_face_stage_kernel<C>), K::SMEM, granted); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL((naf_face_stage_kernel<C>), dim3(64 * K::CL), dim3(K::THREADS), K::SMEM, s, p);
     return hipGetLastError();
 }

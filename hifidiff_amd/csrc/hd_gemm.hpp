@@ -31,12 +31,30 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 // No implicit fused multiply-add in this file: whether `a * b + c` becomes one v_fma_f32 is otherwise decided per
 // instantiation (the same epilogue gave different low bits in two tile shapes), and the XCD-local persistent stages
 // (hd_xcd.hpp) must reproduce these kernels bit for bit.  Every fused operation below is written out (fmaf).
 #pragma clang fp contract(off)
 
 namespace hd {
+
+// The dynamic-LDS limit of a kernel (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE attribute of the function:
+// it is granted once per (kernel instantiation, device) -- `mask` is the instantiation's own function-local word, bit d =
+// granted on device d -- so that a second context on another GPU of the same process gets it as well (thread-safe).
+inline hipError_t grant_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    mask.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
 
 // Tile-shape and fusion rules are FIXED in the product.  The HD_* experiment switches that were used to measure them
 //  are read only when HD_EXPERIMENTS=1 is set; otherwise they are inert (HD_CHAINS, independent sub-batches,
@@ -1698,13 +1716,8 @@ inline hipError_t launch_gemm(const GemmP& p, hipStream_t s) {
     const int ncols = C::PAIR ? p.N / 2 : p.N;
     const int smem = C::SMEM + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0);
     if (smem > 65536) {                                      // above the default dynamic-LDS limit
-        static bool granted = false;
-        if (!granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<C, LD, EP>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            granted = true;
-        }
+        static std::atomic<unsigned long long> granted{0};
+        { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&gemm_kernel<C, LD, EP>), 160 * 1024, granted); if (e != hipSuccess) return e; }
     }
     dim3 grid((p.M + C::BM - 1) / C::BM, (ncols + C::NCOLS - 1) / C::NCOLS, 1);
     hipLaunchKernelGGL((gemm_kernel<C, LD, EP>), grid, dim3(C::THREADS), smem, s, p);
@@ -1741,12 +1754,8 @@ inline hipError_t launch_gemm_deep(const GemmP& p, hipStream_t s) {
 template <class C, class LD, class EP, bool NT, int CPW>
 inline hipError_t launch_skinny_inst(const GemmP& p, hipStream_t s, int smem) {
     if (smem > 65536) {
-        static bool granted = false;
-        if (!granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP, NT, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            granted = true;
-        }
+        static std::atomic<unsigned long long> granted{0};
+        { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&gemm_skinny_kernel<C, LD, EP, NT, CPW>), 160 * 1024, granted); if (e != hipSuccess) return e; }
     }
     const int ncols = (C::TNT == 2) ? p.N / 2 : p.N;
     dim3 grid((p.M + C::BM - 1) / C::BM, (ncols + 31) / 32, 1);

@@ -216,10 +216,13 @@ struct hd_ctx {
     // face-cluster persistent stages of the shallow levels (hd_face.hpp): sync words [flags | gstate] and the pool exchange buffer
     struct FStage { unsigned* sync = nullptr; float* pool_part = nullptr; };
     std::map<int, FStage> fstages;            // by index of the stage's first block
+    bool face_ok = false;                     // decided per context in setup_xcd (HD_NO_FACE / HD_NO_XCD at the time the context is finalized)
     bool face_on = true;                      // run-time switch (hd_set_option "face")
     int face_block_limit = 0;
     unsigned* xcd_tmo_host = nullptr;         // pinned, device-mapped: non-zero after a hand-off wait gave up
     unsigned* xcd_tmo_dev = nullptr;
+    unsigned* abort_dev = nullptr;            // device word: the same code; stage launches read it at entry, poison_if_abort_kernel at the end of a call
+    int stage_test_abort = 0;                 // fault injection (hd_set_option "stage_test_abort"): see XStageP / FStageP::test_abort
 
     // program
     int op_limit = -1, prep_limit = -1;
@@ -1196,7 +1199,7 @@ int build_denoiser_program(hd_ctx* c) {
         sp.X = lv.X; sp.Xb = lv.Xb; sp.sx = lv.sx; sp.G = lv.G; sp.Yb = lv.Yb; sp.sy = lv.sy;
         sp.pooled16 = lv.pooled16; sp.pooled = lv.pooled; sp.S = lv.S; sp.ln_eps = 1e-6f;
         if (gate) { sp.outg16 = lv.Xg; sp.gate_c = gate->gate_c; sp.gate_s = gate->gate_s; sp.add_src = gate->add; }
-        sp.flags = xs->sync; sp.hello = xs->sync + 256; sp.gstate = xs->sync + 512; sp.tmo = c->xcd_tmo_dev;
+        sp.flags = xs->sync; sp.hello = xs->sync + 256; sp.gstate = xs->sync + 512; sp.tmo = c->xcd_tmo_dev; sp.abort_dev = c->abort_dev;
         const bool l3 = lv.C == 1024;
         Op op;
         op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
@@ -1204,7 +1207,7 @@ int build_denoiser_program(hd_ctx* c) {
             if (c->xcd_ok && c->xcd_on && c->chains.size() == 1 && c->film_face_stride == 0) {
                 XStageP r = sp;
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
-                r.phase_limit = c->xcd_phase_limit; r.force_global = c->xcd_force_global;
+                r.phase_limit = c->xcd_phase_limit; r.force_global = c->xcd_force_global; r.test_abort = c->stage_test_abort;
                 return l3 ? launch_xcd_stage<1024, 4>(r, s) : launch_xcd_stage<512, 16>(r, s);
             }
             for (auto& o : *sub) { const hipError_t e = o.run(s); if (e != hipSuccess) return e; }
@@ -1214,10 +1217,9 @@ int build_denoiser_program(hd_ctx* c) {
     };
     // Levels 0 / 1 (latent 16, batch <= 64): a run of blocks as ONE launch with the rows of a face split over a cluster of
     // workgroups (hd_face.hpp); the per-block launches (fused conv1 + chain kernel) stay as the other form of the same op.
-    static const bool no_face = getenv("HD_NO_FACE") != nullptr || getenv("HD_NO_XCD") != nullptr;
     auto add_face_stage = [&](int nblk, const Level& lv, const GateOut* gate, bool want_xb) {
         const int first = bi;
-        const bool shape_ok = c->xcd_ok && !no_face && B <= 64 && ((lv.C == 128 && lv.H == 16) || (lv.C == 256 && lv.H == 8)) && nblk <= XS_MAXBLK && !(gate && gate->add);
+        const bool shape_ok = c->xcd_ok && c->face_ok && B <= 64 && ((lv.C == 128 && lv.H == 16) || (lv.C == 256 && lv.H == 8)) && nblk <= XS_MAXBLK && !(gate && gate->add);
         auto sub = std::make_shared<std::vector<Op>>();
         for (int j = 0; j < nblk; ++j)
             add_naf_block(c, shape_ok ? *sub : prog, c->den_blocks[bi++], lv, nullptr, &np, &cnt, (gate && j == nblk - 1) ? gate : nullptr);
@@ -1238,7 +1240,7 @@ int build_denoiser_program(hd_ctx* c) {
         fp.B = B; fp.nblocks = nblk; fp.blocks = xs->blocks_dev;
         fp.X = lv.X; fp.Xb = want_xb ? lv.Xb : nullptr; fp.ln_eps = 1e-6f;
         if (gate) { fp.outg16 = lv.Xg; fp.gate_c = gate->gate_c; fp.gate_s = gate->gate_s; }
-        fp.pool_part = fs.pool_part; fp.flags = fs.sync; fp.gstate = fs.sync + 64 * 16; fp.tmo = c->xcd_tmo_dev;
+        fp.pool_part = fs.pool_part; fp.flags = fs.sync; fp.gstate = fs.sync + 64 * 16; fp.tmo = c->xcd_tmo_dev; fp.abort_dev = c->abort_dev;
         const bool c128 = lv.C == 128;
         Op op;
         op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
@@ -1246,8 +1248,11 @@ int build_denoiser_program(hd_ctx* c) {
             if (c->xcd_ok && c->face_on && c->chains.size() == 1 && c->film_face_stride == 0) {
                 FStageP r = fp;
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
-                r.block_limit = c->face_block_limit;
-                return c128 ? launch_face_stage<128>(r, s) : launch_face_stage<256>(r, s);
+                r.block_limit = c->face_block_limit; r.test_abort = c->stage_test_abort;
+                const hipError_t e = c128 ? launch_face_stage<128>(r, s) : launch_face_stage<256>(r, s);
+                if (e == hipSuccess) return e;
+                (void)hipGetLastError();                      // (the dynamic-LDS grant was refused: nothing was launched) -> the per-block launches
+                c->face_on = false;
             }
             for (auto& o : *sub) { const hipError_t e = o.run(s); if (e != hipSuccess) return e; }
             return hipSuccess;
@@ -1748,14 +1753,17 @@ static int build_vae_decode(hd_ctx* c, int B, int L, const float* latents, float
 // CUs) and the level geometry is the latent-16 one (4 / 16 pixels per face at levels 3 / 2).  HD_NO_XCD=1 builds the
 // program without them.
 int setup_xcd(hd_ctx* c) {
-    c->xcd_ok = false;
+    c->xcd_ok = false; c->face_ok = false;
     if (c->S != 1 || getenv("HD_NO_XCD")) return HD_OK;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || prop.multiProcessorCount != XS_GROUPS * XS_GROUP_WG) return HD_OK;
     HIPCHECK(c, hipHostMalloc(reinterpret_cast<void**>(&c->xcd_tmo_host), 64, hipHostMallocMapped));
     c->xcd_tmo_host[0] = 0;
     HIPCHECK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->xcd_tmo_dev), c->xcd_tmo_host, 0));
+    if (int rc = dev_alloc(c, &c->abort_dev, 64)) return rc;
+    HIPCHECK(c, hipMemset(c->abort_dev, 0, 64 * sizeof(unsigned)));
     c->xcd_ok = true;
+    c->face_ok = getenv("HD_NO_FACE") == nullptr;        // per context, like xcd_ok: not a process-wide static (fixtures toggle the variable around make_model)
     return HD_OK;
 }
 // the device-side description of a stage (weights only: shared by every workspace), created on first use
@@ -1784,20 +1792,31 @@ int get_xstage(hd_ctx* c, int first_block, int nblocks, hd_ctx::XStage** out) {
     *out = &c->xstages[first_block];
     return HD_OK;
 }
-// A hand-off wait of a persistent stage gave up (a workgroup was not resident, or a fault): results since then are
-// garbage.  Reported once; the context then runs one launch per GEMM.
+// A hand-off wait of a persistent stage gave up (a workgroup was not resident, or a fault).  The call in which that
+// happened hands back NaN (poison_if_abort_kernel at its end; the remaining stage launches of that call step aside at
+// entry), and the failure is reported by the first check that runs after it -- hd_check() behind the caller's
+// synchronisation, or the next hd_eps / hd_sample.  Reported once; the context then runs one launch per GEMM.
 static int check_xcd(hd_ctx* c) {
     if (c->xcd_tmo_host && c->xcd_tmo_host[0]) {
         const unsigned code = c->xcd_tmo_host[0];
+        (void)hipDeviceSynchronize();                      // the failed call's remaining launches still read the words reset below
         c->xcd_tmo_host[0] = 0;
+        if (c->abort_dev) (void)hipMemset(c->abort_dev, 0, 64 * sizeof(unsigned));
         c->xcd_on = false; c->graphs_valid = false;
         for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
         for (auto& kv : c->xstages) (void)hipMemset(kv.second.sync, 0, (size_t)3 * 256 * sizeof(unsigned));
         for (auto& kv : c->fstages) (void)hipMemset(kv.second.sync, 0, (size_t)2 * 64 * 16 * sizeof(unsigned));
         c->face_on = false;
-        HD_FAIL(c, HD_ERR_HIP, "persistent XCD stage: a hand-off wait timed out (code 0x%x); results of the last call are invalid, "
-                               "falling back to one launch per GEMM", code);
+        HD_FAIL(c, HD_ERR_HIP, "persistent stage: a hand-off wait gave up (code 0x%x%s); the results of that call are invalid (NaN), "
+                               "the context now runs one launch per GEMM", code, c->stage_test_abort ? ", injected by stage_test_abort" : "");
     }
+    return HD_OK;
+}
+// End of hd_eps / hd_sample: NaN into the call's result buffer when a stage gave up during the call.
+static int poison_on_abort(hd_ctx* c, float* buf, size_t n, hipStream_t s) {
+    if (!c->abort_dev || !c->xcd_ok) return HD_OK;
+    hipLaunchKernelGGL(poison_if_abort_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->abort_dev, buf, n);
+    HIPCHECK(c, hipGetLastError());
     return HD_OK;
 }
 
@@ -2303,6 +2322,8 @@ int hd_eps(hd_ctx* c, const float* x, const float* timesteps, int n_t, float* ep
         rc = run_ops(c, ch.program, s, ch.index == 0 ? c->op_limit : -1);
         if (rc) return rc;
     }
+    rc = poison_on_abort(c, c->eps, nlat, s);
+    if (rc) return rc;
     HIPCHECK(c, hipMemcpyAsync(eps_out, c->eps, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     return HD_OK;
 }
@@ -2410,6 +2431,8 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
         HIPCHECK(c, hipStreamWaitEvent(s, ch.done, 0));
     }
     if (c->profiling) { HIPCHECK(c, hipEventRecord(c->ev1, s)); c->last_steps = n; }
+    rc = poison_on_abort(c, c->lat, nlat, s);
+    if (rc) return rc;
     HIPCHECK(c, hipMemcpyAsync(x_inout, c->lat, nlat * sizeof(float), hipMemcpyDeviceToDevice, s));
     return HD_OK;
 }
@@ -2491,6 +2514,7 @@ int hd_set_option(hd_ctx* c, const char* key, int value) {
     else if (k == "xcd_force_global") c->xcd_force_global = value;
     else if (k == "face") c->face_on = value != 0;
     else if (k == "face_block_limit") c->face_block_limit = value;
+    else if (k == "stage_test_abort") c->stage_test_abort = value;   // fault injection: 1..: XCD stages, group 0 gives up its wait for phase value - 1; 1000 + b: face stages, face 0, block b
     else HD_FAIL(c, HD_ERR_INVALID, "unknown option %s", key);
     c->graphs_valid = false;                               // captured graphs hold the old choice
     for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
@@ -2503,6 +2527,14 @@ int hd_get_option(hd_ctx* c, const char* key) {
     if (k == "xcd_stages") return (int)c->xstages.size();
     if (k == "face_stages") return (int)c->fstages.size();
     return HD_ERR_INVALID;
+}
+
+// To be called after the caller has synchronised the stream its hd_eps / hd_sample calls ran on: reports (once) a persistent
+// stage that gave up during one of them.  The reference raises RuntimeError synchronously (test_refiner.py:89-91);
+// here the call is asynchronous, its result is NaN-poisoned on the device, and this is where the error surfaces on the host.
+int hd_check(hd_ctx* c) {
+    if (!c) return HD_ERR_INVALID;
+    return check_xcd(c);
 }
 
 int hd_set_profiling(hd_ctx* c, int on) { if (!c) return HD_ERR_INVALID; c->profiling = on != 0; return HD_OK; }

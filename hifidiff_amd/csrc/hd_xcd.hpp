@@ -64,7 +64,10 @@ struct XStageP {
     const float* film; float ln_eps;                     // FiLM row shared by all faces
     unsigned short* outg16; const float* gate_c; const float* gate_s; const float* add_src;   // HCA input after the last block (or NULL)
     unsigned *flags, *hello, *gstate;     // [8][32] words each: one 128-byte line per group
-    unsigned* tmo;                        // host-visible timeout word
+    unsigned* tmo;                        // host-visible timeout word (pinned, device-mapped)
+    unsigned* abort_dev;                  // the same code in device memory: every stage launch reads it at entry and steps aside when it is
+                                          // set (the call's results are then poisoned by poison_if_abort_kernel, hd_kernels.hpp)
+    int test_abort;                       // fault injection (hd_set_option "stage_test_abort"): group 0 gives up its wait for phase test_abort - 1
     int phase_limit;                      // introspection: stop after this many phases (<= 0: all)
     int force_global;                     // test: use the placement-independent hand-off even when the group shares an XCD
 #ifdef HD_STAMPS
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
         const unsigned* src = reinterpret_cast<const unsigned*>(p.blocks);
         unsigned* dst = reinterpret_cast<unsigned*>(L.blk);
         for (int i = tid; i < p.nblocks * (int)(sizeof(XBlockW) / 4); i += XS_THREADS) dst[i] = src[i];
-        if (tid == 0) L.abort = 0u;
+        if (tid == 0) L.abort = __hip_atomic_load((xs_gu32*)p.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an earlier stage of this call gave up
     }
     xs_lds_barrier();
 
@@ -386,9 +389,14 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             const unsigned want = base + (unsigned)ph + 1u;
             for (unsigned spins = 0;; ++spins) {
                 const unsigned v = lane < XS_GROUP_WG ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
-                if (__all((int)(v - want) >= 0)) break;
-                if (spins > XS_SPINS) {
-                    if (lane == 0) { L.abort = 1u; __hip_atomic_store((xs_gu32*)p.tmo, 0x100u + (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                const bool inject = p.test_abort > 0 && ph + 1 == p.test_abort && group == 0;
+                if (!inject && __all((int)(v - want) >= 0)) break;
+                if (spins > XS_SPINS || inject) {
+                    if (lane == 0) {
+                        L.abort = 1u;
+                        __hip_atomic_store((xs_gu32*)p.abort_dev, 0x100u + (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((xs_gu32*)p.tmo, 0x100u + (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -414,7 +422,11 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
             const unsigned v = lane < XS_GROUP_WG ? __hip_atomic_load(hello + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;
             if (__all((v >> 4) == (n + 1u))) { same = __all((v & 15u) == xcc); break; }
             if (spins > XS_SPINS) {
-                if (lane == 0) { L.abort = 1u; __hip_atomic_store((xs_gu32*)p.tmo, 0x80u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                if (lane == 0) {
+                    L.abort = 1u;
+                    __hip_atomic_store((xs_gu32*)p.abort_dev, 0x80u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((xs_gu32*)p.tmo, 0x80u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 break;
             }
             __builtin_amdgcn_s_sleep(1);

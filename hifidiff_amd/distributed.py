@@ -2,8 +2,13 @@
 batch (what `accelerator.prepare(dataloader)` does in the reference, test_refiner.py:174) and the only
 collective is the final gather of the latents (4 KB per face).  `torch.distributed` with backend "nccl"
 is RCCL over xGMI on ROCm; the same code runs on CPU tensors with "gloo" (tests, world_size 2)."""
+import os
+import sys
+
 import torch
 import torch.distributed as dist
+
+_traced = False
 
 
 def shard_range(n_faces, rank, world):
@@ -19,10 +24,16 @@ def shard(t, rank, world):
 
 
 def gather_faces(local, n_faces=None):
-    """All ranks receive the latents of the whole batch, in global face order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """All ranks receive the latents of the whole batch, in global face order.  Without an initialised process group
+    (the plain single-process run) this is the identity; with one -- a world of ONE rank included, which is how the
+    multi-rank path is rehearsed on a one-GPU box -- the latents go through the backend's all_gather."""
+    global _traced
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
+    if os.environ.get("HD_TRACE_GATHER") and not _traced:
+        _traced = True
+        sys.stderr.write("gather_faces: all_gather over %s, world %d, %d faces local\n" % (dist.get_backend(), world, local.shape[0]))
     n_faces = n_faces if n_faces is not None else local.shape[0] * world
     sizes = [shard_range(n_faces, r, world) for r in range(world)]
     if len({hi - lo for lo, hi in sizes}) == 1:

@@ -50,6 +50,15 @@ def _f32c(t, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _version(t):
+    """Version counter of a tensor, or None for tensors that do not track one (created under torch.inference_mode():
+    reading `_version` raises there).  None never matches a cached key, so such tensors are re-prepared on every call."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 class _Engine:
     """Owns the hd_ctx of one (latent_res, device)."""
 
@@ -125,6 +134,8 @@ class _Engine:
             d.is_device = 1 if t.is_cuda else 0
         if self.loaded:      # re-load: a fresh context is simplest (weights are packed once)
             L.hd_destroy(self.ctx)
+            self.ctx = None
+            self.loaded, self.cond_key, self.batch, self.prior_key = False, None, None, None      # nothing usable until finalize succeeds
             self.ctx = self._create(self.device.index)
         with torch.cuda.device(self.device):
             _lib.check(L.hd_load_weights(self.ctx, descs, len(man)), self.ctx)
@@ -213,6 +224,18 @@ class _Engine:
             _lib.check(_lib.lib().hd_eps(self.ctx, x.data_ptr(), t.data_ptr(), t.numel(), out.data_ptr(), _stream(self.device)), self.ctx)
         return out
 
+    def check(self, synchronize=True):
+        """Where the reference's loop would have raised synchronously (test_refiner.py:89-91): forward() / sample() only enqueue
+        work, and a persistent stage launch that has to give up (another tenant kept one of its workgroups off the GPU) fills the
+        result of THAT call with NaN on the device.  This synchronises the current stream and raises RuntimeError once for such
+        a call; the context has then switched itself to one launch per GEMM and the next call is valid again."""
+        if self.ctx is None:
+            return
+        if synchronize:
+            torch.cuda.current_stream(self.device).synchronize()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hd_check(self.ctx), self.ctx)
+
     def __del__(self):
         try:
             if self.ctx is not None:
@@ -279,13 +302,20 @@ class FusedDenoiser(_SubModule):
         # the loop passes the same objects every step -> computed once (identity + version, strong references: never addresses)
         k = getattr(e, "prior_key", None)
         objs = list(facial_priors) + [identity_embedding]
+        # (tensors without a version counter -- torch.inference_mode() -- are never a hit; writes through `.data`, numpy or
+        # DLPack aliases do not bump the counter: pass a new tensor object or call invalidate_conditioning() after such a write)
         hit = (k is not None and len(k) == len(objs) and e.batch == latents.shape[0] and e.cond_key is None and
-               all(o is ko and o._version == kv for o, (ko, kv) in zip(objs, k)))
+               all(o is ko and kv is not None and _version(o) == kv for o, (ko, kv) in zip(objs, k)))
         if not hit:
             e.prior_key = None
             e.prepare_from_priors(facial_priors, identity_embedding)
-            e.prior_key = [(o, o._version) for o in objs]
+            e.prior_key = [(o, _version(o)) for o in objs]
         return UNet2DOutput(e.eps(latents, timesteps))
+
+    def invalidate_conditioning(self):
+        """Forget the cached gates / idc term (after writing into the prior tensors through an alias that does not bump
+        their version counter)."""
+        self._engine.prior_key = None
 
 
 class Denoiser(nn.Module):
@@ -324,6 +354,10 @@ class Denoiser(nn.Module):
     @property
     def engine(self):
         return self._engine
+
+    def check(self, synchronize=True):
+        """Synchronise and raise RuntimeError if a call since the last check handed back NaN-poisoned results (_Engine.check)."""
+        self._engine.check(synchronize)
 
     def forward(self, latents, timesteps):
         e = self._engine
@@ -379,6 +413,10 @@ class FacialRefiner(nn.Module):
     def engine(self):
         return self._engine
 
+    def check(self, synchronize=True):
+        """Synchronise and raise RuntimeError if a call since the last check handed back NaN-poisoned results (_Engine.check)."""
+        self._engine.check(synchronize)
+
     def prepare(self, cr_face, cr_latent):
         """Once-per-batch conditioning (FPG, IDC, HCA gates, idc_conv)."""
         e = self._engine
@@ -388,13 +426,20 @@ class FacialRefiner(nn.Module):
             raise RuntimeError("expected cr_latent (B,4,%d,%d) and cr_face (B,3,128,128), got %s and %s"
                                % (L, L, tuple(cr_latent.shape), tuple(cr_face.shape)))
         k = e.cond_key
-        if (self.cache_conditioning and k is not None and k[0] is cr_face and k[1] == cr_face._version
-                and k[2] is cr_latent and k[3] == cr_latent._version and e.batch == B):
+        vf, vl = _version(cr_face), _version(cr_latent)      # None under torch.inference_mode(): never a hit
+        if (self.cache_conditioning and k is not None and vf is not None and vl is not None and k[0] is cr_face and k[1] == vf
+                and k[2] is cr_latent and k[3] == vl and e.batch == B):
             return
         e.cond_key = None
         e.prepare(cr_latent, cr_face=cr_face)
         # strong references: identity + version, never addresses (a freed tensor's address is handed to the next batch)
-        e.cond_key = (cr_face, cr_face._version, cr_latent, cr_latent._version) if self.cache_conditioning else None
+        e.cond_key = (cr_face, vf, cr_latent, vl) if (self.cache_conditioning and vf is not None and vl is not None) else None
+
+    def invalidate_conditioning(self):
+        """Forget the cached conditioning (after writing into cr_face / cr_latent through `.data`, numpy or a DLPack alias,
+        which does not bump the version counter the cache keys on)."""
+        self._engine.cond_key = None
+        self._engine.prior_key = None
 
     def forward(self, latents, timesteps, cr_face, cr_latent):
         if latents.shape[0] == 0:                          # empty batch: like the reference's convs, an empty result

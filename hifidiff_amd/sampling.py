@@ -38,11 +38,13 @@ def ddim_sample_eager_unconditional(model, latents, scheduler, num_inference_ste
 
 
 @torch.no_grad()
-def sample(model, latents, cr_face, cr_latent, scheduler, noise=None, seed=0, prepare=True):
+def sample(model, latents, cr_face, cr_latent, scheduler, noise=None, seed=0, prepare=True, check=False):
     """Whole loop on the GPU: returns the final latents (a new tensor).
 
     noise: optional [n_steps, B, 4, L, L] tensor of z (DDPM); None -> device Philox(seed).
-    For the unconditional `Denoiser` pass cr_face = cr_latent = None."""
+    For the unconditional `Denoiser` pass cr_face = cr_latent = None.
+    The call only enqueues work.  check=True synchronises the stream afterwards and raises RuntimeError if a persistent
+    stage launch gave up during the loop (the returned latents are NaN in that case either way: `model.check()`)."""
     e = model.engine
     e.ensure(latents.device)
     if latents.shape[0] == 0:                              # empty batch: nothing to sample
@@ -71,4 +73,6 @@ def sample(model, latents, cr_face, cr_latent, scheduler, noise=None, seed=0, pr
     with torch.cuda.device(e.device):
         _lib.check(_lib.lib().hd_sample(e.ctx, x.data_ptr(), ctypes.byref(sch), nptr, int(seed),
                                         torch.cuda.current_stream(e.device).cuda_stream), e.ctx)
+    if check:
+        e.check()
     return x

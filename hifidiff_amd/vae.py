@@ -149,6 +149,8 @@ class AutoencoderKL(nn.Module):
                 d.shape[j] = s
         if self._loaded:
             L.hd_destroy(self._ctx)
+            self._ctx = None
+            self._loaded = False                             # nothing usable until finalize has succeeded
             ctx = ctypes.c_void_p()
             _lib.check(L.hd_vae_create(ctypes.byref(ctx), self._device.index))
             self._ctx = ctx

@@ -154,6 +154,15 @@ int hd_debug_write(hd_ctx* ctx, const char* name, const float* host_in, int64_t 
  * placement-independent hand-off form.  hd_get_option: "xcd" (effective), "xcd_stages" (stages built so far). */
 int hd_set_option(hd_ctx* ctx, const char* key, int value);
 int hd_get_option(hd_ctx* ctx, const char* key);
+/* Error status of the asynchronous calls.  hd_eps / hd_sample only enqueue work; a persistent stage launch that has to give
+ * up a hand-off wait (a workgroup of the stage was not resident: another tenant on the GPU) fills THAT call's result
+ * (eps_out / x_inout) with NaN on the device and raises a host-visible word.  hd_check() -- to be called after the caller
+ * has synchronised the stream, e.g. where the reference's loop would have raised RuntimeError (test_refiner.py:89-91) --
+ * returns HD_ERR_HIP once for such a call (hd_last_error() names the stage and phase) and switches the context to one
+ * launch per GEMM; the next hd_eps / hd_sample performs the same check on entry.  0 when nothing failed.
+ * Fault injection for tests: hd_set_option(ctx, "stage_test_abort", n): n in 1..: group 0 of every XCD-local stage gives up
+ * its wait for phase n - 1; 1000 + b: face 0 of every face-cluster stage gives up the pool wait of block b; 0: off. */
+int hd_check(hd_ctx* ctx);
 /* HIP-event time in ms of the most recent hd_sample's replay loop (0 if profiling is off) and the
  * summed duration of the GEMM launches: used by bench.py for the roofline object */
 int hd_set_profiling(hd_ctx* ctx, int on);

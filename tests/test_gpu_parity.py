@@ -913,3 +913,93 @@ def test_face_cluster_stages_of_the_shallow_levels(gpu, weights16):
     x, crl, crf = [t.cuda() for t in synth.sample_inputs(64, 16)]
     a = sampling.sample(m, x, crf, crl, sch, seed=3)
     assert torch.equal(a, sampling.sample(m, x, crf, crl, sch, seed=3))
+
+
+def test_a_stage_that_gives_up_poisons_its_call_and_reports(gpu, weights16, model2_launches):
+    """a hand-off wait of a persistent stage that gives up must not hand back garbage with rc 0.
+    Fault injection (hd_set_option "stage_test_abort"): group 0 of the first XCD-local stage gives up its wait for phase 3 /
+    face 0 of the first face-cluster stage gives up the pool wait of block 1.  The injected call returns (it only enqueues
+    work) and its result is NaN on the device; check() after the synchronisation raises once and names the code; the context
+    then runs one launch per GEMM and agrees bit for bit with a model built with HD_NO_XCD=1; the remaining stage launches
+    of the failed call step aside at entry (the call does not take n x 0.6 s of spinning)."""
+    import time
+    from hifidiff_amd import _lib, sampling, schedulers, synth
+    L = _lib.lib()
+    B = 5
+    x, crl, crf = [t.cuda() for t in synth.sample_inputs(B, 16)]
+    want = model2_launches(x, 500, crf, crl).sample.clone()
+    sch = schedulers.DDPMScheduler(clip_sample_range=3.0)
+    sch.timesteps = sch.timesteps[:12]
+    want_lat = sampling.sample(model2_launches, x, crf, crl, sch, seed=3).clone()
+    for inject, code in ((4, 0x103), (1001, 0x301)):
+        m = make_model(weights16)
+        good = m(x, 500, crf, crl).sample.clone()
+        m.check()                                                       # nothing failed so far
+        assert L.hd_get_option(m.engine.ctx, b"xcd") == 1 and bool(torch.isfinite(good).all())
+        _opt(m, "stage_test_abort", inject)
+        bad = m(x, 500, crf, crl).sample                               # rc 0: the call only enqueues
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(bad).all()), "the failed call's eps must be NaN, not garbage"
+        with pytest.raises(RuntimeError) as ei:
+            m.check()
+        assert ("0x%x" % code) in str(ei.value) and "stage_test_abort" in str(ei.value), str(ei.value)
+        m.check()                                                       # reported once
+        _opt(m, "stage_test_abort", 0)
+        assert L.hd_get_option(m.engine.ctx, b"xcd") == 0               # fell back
+        again = m(x, 500, crf, crl).sample
+        m.check()
+        assert torch.equal(again, want), rel_l2(again.cpu(), want.cpu())
+        # the same inside a graph-replayed loop: the injected loop hands back NaN latents, quickly; the next loop is valid
+        m2 = make_model(weights16)
+        sampling.sample(m2, x, crf, crl, sch, seed=3, check=True)
+        _opt(m2, "stage_test_abort", inject)
+        t0 = time.perf_counter()
+        lat = sampling.sample(m2, x, crf, crl, sch, seed=3)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 20.0                          # one give-up, not one per remaining stage launch
+        assert bool(torch.isnan(lat).all())
+        with pytest.raises(RuntimeError):
+            sampling.sample(m2, x, crf, crl, sch, seed=3)               # the next call reports it on entry
+        _opt(m2, "stage_test_abort", 0)
+        lat2 = sampling.sample(m2, x, crf, crl, sch, seed=3, check=True)
+        assert torch.equal(lat2, want_lat), rel_l2(lat2.cpu(), want_lat.cpu())
+
+
+def test_inference_mode_tensors_are_served(gpu, model2, inputs2):
+    """tensors created under torch.inference_mode() do not track a version counter (reading `_version` raises):
+    they must be served (as a cache miss, re-prepared every call), through FacialRefiner.forward and FusedDenoiser.forward."""
+    x, crl, crf = inputs2
+    want = model2(x.cuda(), 500, crf.cuda(), crl.cuda()).sample.clone()
+    with torch.inference_mode():
+        xi, cli, cfi = x.cuda(), crl.cuda(), crf.cuda()
+        a = model2(xi, 500, cfi, cli).sample.clone()
+        b = model2(xi, 500, cfi, cli).sample.clone()
+        pri = model2.fpg(cli)
+        emb = model2.idc(cfi)
+        c = model2.denoiser(xi, 500, pri, emb).sample.clone()
+        d = model2.denoiser(xi, 500, pri, emb).sample.clone()
+    assert torch.equal(a, want) and torch.equal(b, want)
+    assert rel_l2(c.cpu(), want.cpu()) <= 1e-6 and torch.equal(c, d)
+    model2.invalidate_conditioning(); model2.denoiser.invalidate_conditioning()
+    assert torch.equal(model2(x.cuda(), 500, crf.cuda(), crl.cuda()).sample, want)
+
+
+def test_multi_rank_code_path_at_one_rank_over_rccl(gpu):
+    """the N > 1 path of bench.py (init_process_group("nccl") = RCCL, shard_range, gather_faces through
+    all_gather, the timing all_reduce) rehearsed on hardware with ONE rank, as a fresh child process (a process that has
+    initialised the GPU never re-execs): rc 0, a world of 1 over RCCL, finite output, the gather went through RCCL."""
+    import json
+    import subprocess
+    env = dict(os.environ, HD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               HD_TRACE_GATHER="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                        "--diffusion-steps", "20", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    cfg = res["config"]
+    assert cfg["rccl_world_size"] == 1 and cfg["output_finite"] is True and res["n_gpus"] == 1
+    assert cfg["faces_per_rank"] == [64] and cfg["diffusion_steps"] == 20
+    assert "gather_faces: all_gather over nccl, world 1" in r.stderr, r.stderr[-2000:]
