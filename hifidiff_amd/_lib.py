@@ -17,9 +17,24 @@ import torch  # noqa: F401  (load order matters, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhifidiff_hip.so")
 # translation units (compiled in parallel, one hipcc each) and the headers they include
-UNITS = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_dispatch_ln.hip", "hd_dispatch_lnface.hip", "hd_dispatch_bf16.hip", "hd_dispatch_misc.hip")]
-SOURCES = UNITS + [os.path.join(_HERE, "csrc", f) for f in ("hd_gemm.hpp", "hd_dispatch.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_vae.hpp", "hd_xcd.hpp", "hd_face.hpp")]
+UNITS = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_stages.hip", "hd_dispatch_ln.hip", "hd_dispatch_lnface.hip", "hd_dispatch_bf16.hip", "hd_dispatch_misc.hip")]
+SOURCES = UNITS + [os.path.join(_HERE, "csrc", f) for f in ("hd_gemm.hpp", "hd_dispatch.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_vae.hpp", "hd_stage_api.hpp", "hd_xcd.hpp", "hd_xcd2.hpp", "hd_face.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
+
+
+def unit_deps(unit):
+    """The unit and every file it includes with #include "..." (recursively): what its object file depends on."""
+    import re
+    seen, todo = [], [unit]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        with open(f) as fh:
+            for inc in re.findall(r'^\s*#include\s+"([^"]+)"', fh.read(), flags=re.M):
+                todo.append(os.path.join(os.path.dirname(f), inc))
+    return seen
 
 EXPORTS = [
     "hd_create", "hd_create_unconditional", "hd_prepare_unconditional", "hd_cr_create", "hd_cr_forward", "hd_vae_create", "hd_vae_encode", "hd_vae_decode", "hd_destroy", "hd_last_error", "hd_load_weights", "hd_finalize_weights", "hd_prepare",
@@ -50,12 +65,15 @@ def build(force=False, verbose=False):
     objdir = os.path.join(_HERE, "csrc", "build")
     os.makedirs(objdir, exist_ok=True)
     objs = [os.path.join(objdir, os.path.splitext(os.path.basename(u))[0] + ".o") for u in UNITS]
-    cmds = [[hipcc] + flags + ["-c", u, "-o", o] for u, o in zip(UNITS, objs)]
+    # a unit is recompiled when it or a header it includes is newer than its object file
+    stale = [(u, o) for u, o in zip(UNITS, objs)
+             if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(d) for d in unit_deps(u))]
+    cmds = [[hipcc] + flags + ["-c", u, "-o", o] for u, o in stale]
     if verbose:
         for c in cmds:
             print(" ".join(c))
     procs = [subprocess.Popen(c) for c in cmds]                 # the kernel instantiations dominate: one process per unit
-    failed = [u for u, pr in zip(UNITS, procs) if pr.wait() != 0]
+    failed = [u for (u, _), pr in zip(stale, procs) if pr.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(os.path.basename(f) for f in failed))
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs

@@ -26,23 +26,6 @@
 
 namespace hd {
 
-struct FStageP {
-    int B, nblocks;                        // faces (<= 64), blocks of this run
-    const XBlockW* blocks;                 // device array [nblocks]
-    float* X;                              // [M][C] fp32: entry, per-block hand-off of x', exit
-    unsigned short* Xb;                    // exit: bf16 copy of x' (what the down conv gathers), or NULL
-    unsigned short* outg16; const float *gate_c, *gate_s;     // exit: (x') * (1 + w_c + w_s) for the HCA conv, or NULL
-    float* pool_part;                      // [faces][CL][C] channel sums of the gate of each workgroup's rows
-    const float* film; float ln_eps;
-    unsigned *flags, *gstate;              // [64 faces][16] words each
-    unsigned* tmo;                         // host-visible timeout word (pinned, device-mapped)
-    unsigned* abort_dev;                   // the same code in device memory, read at entry by every stage launch (hd_xcd.hpp)
-    int test_abort;                        // fault injection: 1000 + b = face 0 gives up its pool wait of block b
-    int block_limit;                       // introspection: stop after this many blocks (<= 0: all)
-#ifdef HD_STAMPS
-    unsigned long long* stamps;            // [block][workgroup][8]
-#endif
-};
 #ifdef HD_STAMPS
 #define HD_FSTAMP(i) do { if (p.stamps && tid == 0) p.stamps[((size_t)blk * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else

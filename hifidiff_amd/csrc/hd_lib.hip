@@ -21,8 +21,7 @@
 #include "hd_gemm.hpp"
 #include "hd_kernels.hpp"
 #include "hd_vae.hpp"
-#include "hd_xcd.hpp"
-#include "hd_face.hpp"
+#include "hd_stage_api.hpp"
 
 using namespace hd;
 
@@ -219,6 +218,7 @@ struct hd_ctx {
     bool face_ok = false;                     // decided per context in setup_xcd (HD_NO_FACE / HD_NO_XCD at the time the context is finalized)
     bool face_on = true;                      // run-time switch (hd_set_option "face")
     int face_block_limit = 0;
+    int stage_limit_first = -1;               // introspection: the limits above apply only to the stage whose first block has this index (< 0: to all)
     unsigned* xcd_tmo_host = nullptr;         // pinned, device-mapped: non-zero after a hand-off wait gave up
     unsigned* xcd_tmo_dev = nullptr;
     unsigned* abort_dev = nullptr;            // device word: the same code; stage launches read it at entry, poison_if_abort_kernel at the end of a call
@@ -1203,12 +1203,13 @@ int build_denoiser_program(hd_ctx* c) {
         const bool l3 = lv.C == 1024;
         Op op;
         op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
-        op.run = [c, chp, sp, sub, l3](hipStream_t s) -> hipError_t {
+        op.run = [c, chp, sp, sub, l3, first](hipStream_t s) -> hipError_t {
             if (c->xcd_ok && c->xcd_on && c->chains.size() == 1 && c->film_face_stride == 0) {
                 XStageP r = sp;
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
-                r.phase_limit = c->xcd_phase_limit; r.force_global = c->xcd_force_global; r.test_abort = c->stage_test_abort;
-                return l3 ? launch_xcd_stage<1024, 4>(r, s) : launch_xcd_stage<512, 16>(r, s);
+                r.phase_limit = (c->stage_limit_first < 0 || c->stage_limit_first == first) ? c->xcd_phase_limit : 0;
+                r.force_global = c->xcd_force_global; r.test_abort = c->stage_test_abort;
+                return run_xcd_stage(l3 ? 1024 : 512, r, s);
             }
             for (auto& o : *sub) { const hipError_t e = o.run(s); if (e != hipSuccess) return e; }
             return hipSuccess;
@@ -1244,12 +1245,13 @@ int build_denoiser_program(hd_ctx* c) {
         const bool c128 = lv.C == 128;
         Op op;
         op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
-        op.run = [c, chp, fp, sub, c128](hipStream_t s) -> hipError_t {
+        op.run = [c, chp, fp, sub, c128, first](hipStream_t s) -> hipError_t {
             if (c->xcd_ok && c->face_on && c->chains.size() == 1 && c->film_face_stride == 0) {
                 FStageP r = fp;
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
-                r.block_limit = c->face_block_limit; r.test_abort = c->stage_test_abort;
-                const hipError_t e = c128 ? launch_face_stage<128>(r, s) : launch_face_stage<256>(r, s);
+                r.block_limit = (c->stage_limit_first < 0 || c->stage_limit_first == first) ? c->face_block_limit : 0;
+                r.test_abort = c->stage_test_abort;
+                const hipError_t e = run_face_stage(c128 ? 128 : 256, r, s);
                 if (e == hipSuccess) return e;
                 (void)hipGetLastError();                      // (the dynamic-LDS grant was refused: nothing was launched) -> the per-block launches
                 c->face_on = false;
@@ -2514,6 +2516,7 @@ int hd_set_option(hd_ctx* c, const char* key, int value) {
     else if (k == "xcd_force_global") c->xcd_force_global = value;
     else if (k == "face") c->face_on = value != 0;
     else if (k == "face_block_limit") c->face_block_limit = value;
+    else if (k == "stage_limit_first") c->stage_limit_first = value;
     else if (k == "stage_test_abort") c->stage_test_abort = value;   // fault injection: 1..: XCD stages, group 0 gives up its wait for phase value - 1; 1000 + b: face stages, face 0, block b
     else HD_FAIL(c, HD_ERR_INVALID, "unknown option %s", key);
     c->graphs_valid = false;                               // captured graphs hold the old choice

@@ -37,44 +37,11 @@
 #include <type_traits>
 
 #include "hd_gemm.hpp"
+#include "hd_stage_api.hpp"
 
 #pragma clang fp contract(off)                         // as hd_gemm.hpp: every fused multiply-add is written out
 
 namespace hd {
-
-struct XBlockW {
-    const uint4 *w1, *wsca, *w3, *w4, *w5;           // packed bf16 B fragments (hd_kernels.hpp: pack_weight_kernel)
-    const float *b1, *bsca, *b3, *b4, *b5, *beta, *gamma;
-    const float *dw_w, *dw_b;                         // depthwise 3x3 weights tap-major [9][2C], bias [2C]
-    int film_off, pad_;                               // this block's 4C FiLM values: [bias_att | gain_att | bias_ffn | gain_ffn]
-};
-
-constexpr int XS_MAXBLK = 8;
-constexpr int XS_THREADS = 512;
-constexpr int XS_GROUPS = 8, XS_GROUP_WG = 32, XS_FACES = 8;      // 8 XCDs x 32 CUs; faces per group
-constexpr unsigned XS_SPINS = 1u << 21;                            // polls (>= 0.3 us each) before a wait gives up
-
-struct XStageP {
-    int B, nblocks;                       // faces in the batch (<= 64), blocks in this stage (<= XS_MAXBLK)
-    const XBlockW* blocks;                // device array [nblocks]
-    // level buffers, standard layouts ([rows][C] channels-last over the whole batch)
-    float* X; unsigned short* Xb; float2* sx;            // residual stream: entry (from the previous launch) and exit
-    unsigned short* G; unsigned short* Yb; float2* sy;   // hand-off buffers between phases
-    unsigned short* pooled16; float* pooled; float* S;   // pooled16: hand-off; pooled / S: introspection copies (may be NULL)
-    const float* film; float ln_eps;                     // FiLM row shared by all faces
-    unsigned short* outg16; const float* gate_c; const float* gate_s; const float* add_src;   // HCA input after the last block (or NULL)
-    unsigned *flags, *hello, *gstate;     // [8][32] words each: one 128-byte line per group
-    unsigned* tmo;                        // host-visible timeout word (pinned, device-mapped)
-    unsigned* abort_dev;                  // the same code in device memory: every stage launch reads it at entry and steps aside when it is
-                                          // set (the call's results are then poisoned by poison_if_abort_kernel, hd_kernels.hpp)
-    int test_abort;                       // fault injection (hd_set_option "stage_test_abort"): group 0 gives up its wait for phase test_abort - 1
-    int phase_limit;                      // introspection: stop after this many phases (<= 0: all)
-    int force_global;                     // test: use the placement-independent hand-off even when the group shares an XCD
-#ifdef HD_STAMPS
-    unsigned long long* stamps;           // [phase][workgroup][8]: 0 start, 1 barrier passed, 2 K loop done, 3 epilogue stores issued, 4 drained, 5 published
-    int dbg_no_a, dbg_no_w;               // timing-only what-ifs (results are garbage): activation loads through zero-record descriptors / no weight loads
-#endif
-};
 
 template <int C_, int HW_>
 struct XcdCfg {

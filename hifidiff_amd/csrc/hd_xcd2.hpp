@@ -37,25 +37,6 @@ namespace hd {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-struct X2StageP {
-    int B, nblocks;
-    const XBlockW* blocks;                 // device array [nblocks]; weights in the 16x16x32 packing (pack_weight16_kernel)
-    float* X; unsigned short* Xb; const float2* sx;      // entry (standard layouts, sx: [M][C/32] partials of 32) and exit (X, Xb)
-    uint4 *hX, *hG, *hY;                   // hand-off, fragment order: [row block][C/32][64 lanes] uint4
-    float2 *hsx, *hsy;                     // hand-off statistics [row][C/16]: (mean, M2) of 16 channels
-    unsigned short* pooled16;              // hand-off [B][C] bf16 (standard)
-    // introspection copies in the standard layouts (written by the phase a phase_limit stops at; may be NULL)
-    unsigned short *dG, *dYb; float *dpooled, *dS;
-    const float* film; float ln_eps;
-    unsigned short* outg16; const float *gate_c, *gate_s, *add_src;
-    unsigned *flags, *hello, *gstate;      // [8 groups][128] | [8][32] | [8][32]
-    unsigned *tmo, *abort_dev; int test_abort;
-    int phase_limit, force_global;
-#ifdef HD_STAMPS
-    unsigned long long* stamps;            // [phase][workgroup][8] of compute wave 0
-#endif
-};
-
 template <int C_, int HW_>
 struct X2Cfg {
     static constexpr int C = C_, HW = HW_;

@@ -150,7 +150,9 @@ int64_t hd_debug_read(hd_ctx* ctx, const char* name, float* host_out, int64_t ma
 int hd_debug_write(hd_ctx* ctx, const char* name, const float* host_in, int64_t n_elems);
 /* Run-time switches that select between equivalent launch programs of the same arithmetic (tests compare them bit for
  * bit; no reference interface corresponds): "xcd" 1/0 = levels 2 / 3 as XCD-local persistent launches (hd_xcd.hpp) or one
- * launch per GEMM; "xcd_phase_limit" n = stop every persistent stage after n phases (0: all); "xcd_force_global" 1 = its
+ * launch per GEMM; "face" 1/0 the same for levels 0 / 1 (hd_face.hpp); "xcd_phase_limit" n / "face_block_limit" n = stop
+ * the persistent stages after n phases / blocks (0: all), "stage_limit_first" i = only the stage whose first block has index
+ * i (-1: every stage) -- tests read a stage's residual stream block by block; "xcd_force_global" 1 = its
  * placement-independent hand-off form.  hd_get_option: "xcd" (effective), "xcd_stages" (stages built so far). */
 int hd_set_option(hd_ctx* ctx, const char* key, int value);
 int hd_get_option(hd_ctx* ctx, const char* key);

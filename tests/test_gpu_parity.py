@@ -762,6 +762,26 @@ def test_teacher_forced_op_parity(gpu, weights16, model2_launches):
         assert worst["fp32"] <= 3e-4 and worst["bf16"] <= 3e-3, (B, worst)
 
 
+def test_persistent_stages_block_by_block_against_oracle(gpu, weights16):
+    """The eight persistent stages of the program the benchmark times (63 launches: hd_face.hpp levels 0 / 1, hd_xcd.hpp levels
+    2 / 3), each stopped after b blocks (`face_block_limit` / `xcd_phase_limit`): the oracle's arithmetic for ONE
+    ConditionalNAFBlock (conditional_naf.py:108-136, bf16-operand emulation) applied to the residual stream the stage itself had
+    reached before the block, against what the stage holds after it (x' itself as an fp32 output, and the block's own
+    contribution x' - x, which passes through the bf16-stored gate tiles, under the bf16 bound) -- 24 blocks + the 8 exit copies
+    (bf16 / gated HCA input), at batch 2 and at the benchmark batch.  The stages are checked on their own: nothing here refers to the per-GEMM launches.
+    Bounds: fp32 outputs <= 3e-4, bf16-stored <= 3e-3."""
+    import op_forced
+    from hifidiff_amd import synth
+    m = make_model(weights16)
+    for B in (2, 64):
+        x, crl, crf = synth.sample_inputs(B, 16)
+        rep = []
+        worst = op_forced.stage_forced_scan(m, weights16, x, crl, crf, 500.0, rep)
+        assert worst["stages"] == 8 and len(rep) == 56, (worst, len(rep))
+        assert not [r for r in rep if "<<<<<<" in r], [r for r in rep if "<<<<<<" in r][:8]
+        assert worst["fp32"] <= 3e-4 and worst["bf16"] <= 3e-3, (B, worst)
+
+
 def test_eps_at_the_benchmark_batch_against_oracle(gpu, weights16):
     """64 faces, the kernel instantiations the benchmark runs (XCD-local stages included), directly against the bf16-emulating
     oracle: t in {999, 500, 0} with one timestep for all faces, and a timestep per face.  Measured r03: 2.1e-3."""

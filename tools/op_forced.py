@@ -206,6 +206,90 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
     return worst
 
 
+def stage_forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e-3):
+    """The persistent stages of the DEFAULT program (63 launches at latent 16, batch <= 64: hd_face.hpp levels 0 / 1, hd_xcd.hpp /
+    hd_xcd2.hpp levels 2 / 3), block by block: the stage is stopped after b blocks (`face_block_limit` / `xcd_phase_limit`
+    = 5 b), the residual stream it has reached is read back, the oracle's arithmetic for block b + 1 alone
+    (conditional_naf.py:108-136, bf16-operand emulation) is applied to exactly those values and compared with what the stage
+    holds after b + 1 blocks.  The stages therefore need not share a single bit with the per-GEMM launches.  At the end of a
+    stage the bf16 copy / the gated HCA input it emits are checked against the stage's own fp32 output."""
+    L = _lib.lib()
+    e = model.engine
+    ctx = e.ctx
+    B, latent = x.shape[0], e.latent_res
+    e.prepare(crl.cuda(), cr_face=crf.cuda())
+    xd = x.cuda()
+    n = L.hd_num_ops(ctx, 0)
+    names = [L.hd_debug_op_name(ctx, 0, i).decode() for i in range(n)]
+    tt = O.normalize_timesteps(t, B)
+    temb = O.time_embedding(P, tt)
+    idc = _read(L, ctx, "idc")
+    gate_c = {i: _read(L, ctx, f"wc{i}") for i in range(5)}
+    gate_s = {i: _read(L, ctx, f"ws{i}") for i in range(5)}
+    worst = {"fp32": 0.0, "bf16": 0.0}
+    nstages = 0
+
+    def run_to(i, face_limit=0, phase_limit=0, first=-1):
+        _lib.check(L.hd_set_option(ctx, b"stage_limit_first", first), ctx)          # the limits stop THIS stage only
+        _lib.check(L.hd_set_option(ctx, b"face_block_limit", face_limit), ctx)
+        _lib.check(L.hd_set_option(ctx, b"xcd_phase_limit", phase_limit), ctx)
+        L.hd_debug_limit_ops(ctx, 0, i)
+        e.eps(xd, t)
+
+    def check(i, name, what, got, want, stored_bf16):
+        rel, mx = _rel(got, want)
+        kind = "bf16" if stored_bf16 else "fp32"
+        lim = bf16_bound if stored_bf16 else fp32_bound
+        worst[kind] = max(worst[kind], rel if rel == rel else 1e9)
+        report.append(f"{i:3d} {name:42s} {what:8s} rel {rel:.3e} maxabs {mx:.3e} ({kind} <= {lim:.0e}){'' if rel <= lim else '  <<<<<<'}")
+
+    gated_last = {"denoiser.decoders.0.1": 1, "denoiser.decoders.1.1": 2, "denoiser.decoders.2.1": 3, "denoiser.decoders.3.1": 4}
+    enc_blocks = [2, 2, 4, 8]
+    try:
+        for i, name in enumerate(names):
+            parts = name.split(".")
+            if parts[0] != "denoiser" or parts[-1] != "conv5" or parts[1] == "middle_blks":
+                continue
+            if i > 0 and names[i - 1].startswith(".".join(parts[:-1]) + "."):
+                continue                                              # a per-GEMM conv5 launch, not a stage
+            l, C, H = level_of(name, latent)
+            sl = str(l)
+            M = B * H * H
+            nblk = enc_blocks[l] if parts[1] == "encoders" else 2
+            assert int(parts[3]) == nblk - 1, name
+            grp = ".".join(parts[:3])
+            first = sum(enc_blocks[:l]) if parts[1] == "encoders" else 16 + 8 + 2 * int(parts[2])     # index of the stage's first block
+            nstages += 1
+            run_to(i)
+            cur = _nchw(_read(L, ctx, "X" + sl), B, C, H)
+            for b in range(nblk):
+                p = f"{grp}.{b}"
+                want = O.cond_naf_block(P, p, cur, temb, prec=PR)
+                lim = 0 if b == nblk - 1 else b + 1
+                run_to(i + 1, face_limit=lim, phase_limit=5 * lim, first=first)
+                got = _read(L, ctx, "X" + sl)[:M * C]
+                check(i, p + " (stage)", "X", got, _rows(want), False)
+                # the block's own contribution x' - x (the residual carries most of the norm of x'): passes through the bf16-stored
+                # gate tiles, hence the bf16 bound
+                check(i, p + " (stage)", "X'-X", got - _rows(cur), _rows(want - cur), True)
+                cur = _nchw(got, B, C, H)
+            # exit copies of the whole stage
+            if model.engine.conditional and f"{grp}.{nblk - 1}" in gated_last:
+                gi = gated_last[f"{grp}.{nblk - 1}"]
+                wc = gate_c[gi][:B * C].reshape(B, C, 1, 1)
+                ws = gate_s[gi][:M].reshape(B, 1, H, H)
+                check(i, name, "Xg", _read(L, ctx, "Xg" + sl)[:M * C], _rows(PR.q(cur * (1.0 + wc + ws))), True)
+            else:
+                check(i, name, "Xb", _read(L, ctx, "Xb" + sl)[:M * C], _rows(PR.q(cur)), True)
+    finally:
+        L.hd_set_option(ctx, b"stage_limit_first", -1)
+        L.hd_set_option(ctx, b"face_block_limit", 0)
+        L.hd_set_option(ctx, b"xcd_phase_limit", 0)
+        L.hd_debug_limit_ops(ctx, 0, -1)
+    worst["stages"] = nstages
+    return worst
+
+
 def main():
     import argparse
     from hifidiff_amd import synth
@@ -215,17 +299,19 @@ def main():
     ap.add_argument("--latent", type=int, default=16)
     ap.add_argument("--t", type=float, default=500.0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "op_forced.txt"))
+    ap.add_argument("--stages", action="store_true", help="the persistent stages of the default program, block by block (stage_forced_scan)")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
     P = synth.refiner_state_dict(a.latent)
-    os.environ["HD_NO_XCD"] = "1"
+    if not a.stages:
+        os.environ["HD_NO_XCD"] = "1"
     m = FacialRefiner(a.latent); m.load_state_dict(P); m.to("cuda")
     x, crl, crf = synth.sample_inputs(a.batch, a.latent)
     report = []
-    worst = forced_scan(m, P, x, crl, crf, a.t, report)
+    worst = (stage_forced_scan if a.stages else forced_scan)(m, P, x, crl, crf, a.t, report)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
-        f.write(f"teacher-forced op parity, batch {a.batch}, latent {a.latent}, t {a.t}: worst fp32 {worst['fp32']:.3e}, worst bf16-stored {worst['bf16']:.3e}\n")
+        f.write(f"teacher-forced {'stage (block by block)' if a.stages else 'op'} parity, batch {a.batch}, latent {a.latent}, t {a.t}: worst fp32 {worst['fp32']:.3e}, worst bf16-stored {worst['bf16']:.3e}\n")
         f.write("\n".join(report) + "\n")
     bad = [r for r in report if "<<<<<<" in r or "no rule" in r]
     print("\n".join(bad[:40]))
