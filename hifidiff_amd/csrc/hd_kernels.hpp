@@ -55,6 +55,23 @@ __global__ void pack_weight_kernel(const PackP p) {
     }
 }
 
+// 1x1 conv weight [N][K] fp32 -> bf16 in the A-operand order of v_mfma_f32_16x16x32_bf16 (hd_xcd2.hpp: the WEIGHTS are the A operand,
+// 16 output channels x 32 k per fragment): dst[(mb * K/32 + ks) * 64 + lane] = W[mb*16 + (lane & 15)][ks*32 + 8*(lane >> 4) .. + 7]
+__global__ void pack_weight16_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int N, int K) {
+    const int ksteps = K >> 5;
+    const size_t total = (size_t)(N >> 4) * ksteps * 64;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63);
+        const size_t tk = e >> 6;
+        const int ks = (int)(tk % ksteps), mb = (int)(tk / ksteps);
+        const float* q = src + (size_t)(mb * 16 + (lane & 15)) * K + ks * 32 + 8 * (lane >> 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = q[j];
+        dst[e] = pack8(v);
+    }
+}
+
 // depthwise weights [2C][9] -> tap-major [9][2C]: the fused conv1 epilogue reads them with one coalesced load per tap
 __global__ void dw_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT, int n2c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -207,10 +207,20 @@ struct hd_ctx {
     uint64_t vae_seed = 0;
 
     // XCD-local persistent stages (hd_xcd.hpp): latent 16, batch <= 64, one chain, one FiLM row for all faces
-    struct XStage { XBlockW* blocks_dev = nullptr; unsigned* sync = nullptr; int nblocks = 0; };   // sync: flags | hello | gstate, 256 words each
+    struct XStage {
+        XBlockW* blocks_dev = nullptr; unsigned* sync = nullptr; int nblocks = 0;      // sync: flags | hello | gstate, 256 words each
+        // autonomous-wave form (hd_xcd2.hpp): the same blocks with the GEMM weights in the 16x16x32 A-operand packing, fragment-order
+        // hand-off buffers (64 faces), sync2: flags [8][128] | hello [8][32] | gstate [8][32]
+        XBlockW* blocks2_dev = nullptr; unsigned* sync2 = nullptr;
+        uint4 *hX = nullptr, *hG = nullptr, *hY = nullptr; float2 *hsx = nullptr, *hsy = nullptr;
+    };
     std::map<int, XStage> xstages;            // by index of the stage's first block in den_blocks
     bool xcd_ok = false;                      // the device and the network allow it (setup_xcd)
     bool xcd_on = true;                       // run-time switch (hd_set_option "xcd"): off = the per-GEMM launches of the same program
+    int xcd2_mask = 0;                        // levels whose stages also exist in the autonomous-wave form (hd_xcd2.hpp): bit 0 level 2, bit 1 level 3.
+                                              // Default 1: measured faster at level 2 (80 vs 90 us for 4 blocks), slower at level 3 (232 vs 217 us
+                                              // for 8); HD_XCD2=0..3 overrides (experiments)
+    bool xcd2_on = true;                      // run-time switch (hd_set_option "xcd2") between the two forms of the XCD-local stages
     int xcd_phase_limit = 0, xcd_force_global = 0;
     // face-cluster persistent stages of the shallow levels (hd_face.hpp): sync words [flags | gstate] and the pool exchange buffer
     struct FStage { unsigned* sync = nullptr; float* pool_part = nullptr; };
@@ -1201,9 +1211,25 @@ int build_denoiser_program(hd_ctx* c) {
         if (gate) { sp.outg16 = lv.Xg; sp.gate_c = gate->gate_c; sp.gate_s = gate->gate_s; sp.add_src = gate->add; }
         sp.flags = xs->sync; sp.hello = xs->sync + 256; sp.gstate = xs->sync + 512; sp.tmo = c->xcd_tmo_dev; sp.abort_dev = c->abort_dev;
         const bool l3 = lv.C == 1024;
+        X2StageP sp2{};
+        if (xs->blocks2_dev) {
+            sp2.B = B; sp2.nblocks = nblk; sp2.blocks = xs->blocks2_dev;
+            sp2.X = lv.X; sp2.Xb = lv.Xb; sp2.sx = lv.sx; sp2.hX = xs->hX; sp2.hG = xs->hG; sp2.hY = xs->hY; sp2.hsx = xs->hsx; sp2.hsy = xs->hsy;
+            sp2.pooled16 = lv.pooled16; sp2.dG = lv.G; sp2.dYb = lv.Yb; sp2.dpooled = lv.pooled; sp2.dS = lv.S; sp2.ln_eps = 1e-6f;
+            if (gate) { sp2.outg16 = lv.Xg; sp2.gate_c = gate->gate_c; sp2.gate_s = gate->gate_s; sp2.add_src = gate->add; }
+            sp2.flags = xs->sync2; sp2.hello = xs->sync2 + 1024; sp2.gstate = xs->sync2 + 1280; sp2.tmo = c->xcd_tmo_dev; sp2.abort_dev = c->abort_dev;
+        }
+        const bool have2 = xs->blocks2_dev != nullptr;
         Op op;
         op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
-        op.run = [c, chp, sp, sub, l3, first](hipStream_t s) -> hipError_t {
+        op.run = [c, chp, sp, sp2, have2, sub, l3, first](hipStream_t s) -> hipError_t {
+            if (have2 && c->xcd_ok && c->xcd_on && c->xcd2_on && c->chains.size() == 1 && c->film_face_stride == 0) {
+                X2StageP r = sp2;
+                r.film = c->film_from_cur ? chp->film_cur : c->film_table;
+                r.phase_limit = (c->stage_limit_first < 0 || c->stage_limit_first == first) ? c->xcd_phase_limit : 0;
+                r.force_global = c->xcd_force_global; r.test_abort = c->stage_test_abort;
+                return run_xcd2_stage(l3 ? 1024 : 512, r, s);
+            }
             if (c->xcd_ok && c->xcd_on && c->chains.size() == 1 && c->film_face_stride == 0) {
                 XStageP r = sp;
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
@@ -1765,6 +1791,7 @@ int setup_xcd(hd_ctx* c) {
     if (int rc = dev_alloc(c, &c->abort_dev, 64)) return rc;
     HIPCHECK(c, hipMemset(c->abort_dev, 0, 64 * sizeof(unsigned)));
     c->xcd_ok = true;
+    c->xcd2_mask = getenv("HD_XCD2") ? (atoi(getenv("HD_XCD2")) & 3) : 1;
     c->face_ok = getenv("HD_NO_FACE") == nullptr;        // per context, like xcd_ok: not a process-wide static (fixtures toggle the variable around make_model)
     return HD_OK;
 }
@@ -1790,6 +1817,37 @@ int get_xstage(hd_ctx* c, int first_block, int nblocks, hd_ctx::XStage** out) {
     if (rc) return rc;
     HIPCHECK(c, hipMemcpy(st.blocks_dev, host.data(), host.size() * sizeof(XBlockW), hipMemcpyHostToDevice));
     HIPCHECK(c, hipMemset(st.sync, 0, (size_t)3 * 256 * sizeof(unsigned)));
+    const int C = c->den_blocks[first_block].C, HW = (C == 1024) ? 4 : 16;
+    if (c->xcd2_mask & (C == 1024 ? 2 : 1)) {
+        // the five 1x1 convs of every block once more, in the A-operand order of the 16x16x32 MFMA (hd_xcd2.hpp)
+        c->ws_scope = false;
+        for (int j = 0; j < nblocks; ++j) {
+            const BlockW& bw = c->den_blocks[first_block + j];
+            const char* conv[5] = {".conv1", ".sca.1", ".conv3", ".conv4", ".conv5"};
+            const uint4** dst[5] = {&host[j].w1, &host[j].wsca, &host[j].w3, &host[j].w4, &host[j].w5};
+            for (int k = 0; k < 5; ++k) {
+                const RawTensor* w = find_raw(c, bw.name + conv[k] + ".weight");
+                if (!w || (int)w->shape[1] != C) { c->ws_scope = ws; HD_FAIL(c, HD_ERR_WEIGHTS, "missing %s%s.weight", bw.name.c_str(), conv[k]); }
+                const int N = (int)w->shape[0];
+                uint4* d = nullptr;
+                if (int r2 = dev_alloc(c, &d, (size_t)N * C / 8)) { c->ws_scope = ws; return r2; }
+                hipLaunchKernelGGL(pack_weight16_kernel, dim3(1024), dim3(256), 0, 0, w->dev, d, N, C);
+                *dst[k] = d;
+            }
+        }
+        int r2 = dev_alloc(c, &st.blocks2_dev, (size_t)nblocks);
+        r2 |= dev_alloc(c, &st.sync2, (size_t)2048);
+        const size_t hn = (size_t)64 * HW * C / 8;
+        r2 |= dev_alloc(c, &st.hX, hn); r2 |= dev_alloc(c, &st.hG, hn); r2 |= dev_alloc(c, &st.hY, hn);
+        r2 |= dev_alloc(c, &st.hsx, (size_t)64 * HW * (C / 16)); r2 |= dev_alloc(c, &st.hsy, (size_t)64 * HW * (C / 16));
+        c->ws_scope = ws;
+        if (r2) return r2;
+        HIPCHECK(c, hipGetLastError());
+        HIPCHECK(c, hipMemcpy(st.blocks2_dev, host.data(), host.size() * sizeof(XBlockW), hipMemcpyHostToDevice));
+        HIPCHECK(c, hipMemset(st.sync2, 0, (size_t)2048 * sizeof(unsigned)));
+        HIPCHECK(c, hipMemset(st.hX, 0, hn * 16)); HIPCHECK(c, hipMemset(st.hG, 0, hn * 16)); HIPCHECK(c, hipMemset(st.hY, 0, hn * 16));
+        HIPCHECK(c, hipMemset(st.hsx, 0, (size_t)64 * HW * (C / 16) * 8)); HIPCHECK(c, hipMemset(st.hsy, 0, (size_t)64 * HW * (C / 16) * 8));
+    }
     c->xstages[first_block] = st;
     *out = &c->xstages[first_block];
     return HD_OK;
@@ -1806,7 +1864,10 @@ static int check_xcd(hd_ctx* c) {
         if (c->abort_dev) (void)hipMemset(c->abort_dev, 0, 64 * sizeof(unsigned));
         c->xcd_on = false; c->graphs_valid = false;
         for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;
-        for (auto& kv : c->xstages) (void)hipMemset(kv.second.sync, 0, (size_t)3 * 256 * sizeof(unsigned));
+        for (auto& kv : c->xstages) {
+            (void)hipMemset(kv.second.sync, 0, (size_t)3 * 256 * sizeof(unsigned));
+            if (kv.second.sync2) (void)hipMemset(kv.second.sync2, 0, (size_t)2048 * sizeof(unsigned));
+        }
         for (auto& kv : c->fstages) (void)hipMemset(kv.second.sync, 0, (size_t)2 * 64 * 16 * sizeof(unsigned));
         c->face_on = false;
         HD_FAIL(c, HD_ERR_HIP, "persistent stage: a hand-off wait gave up (code 0x%x%s); the results of that call are invalid (NaN), "
@@ -2512,6 +2573,7 @@ int hd_set_option(hd_ctx* c, const char* key, int value) {
     if (!c || !key) return HD_ERR_INVALID;
     const std::string k = key;
     if (k == "xcd") c->xcd_on = value != 0;
+    else if (k == "xcd2") c->xcd2_on = value != 0;
     else if (k == "xcd_phase_limit") c->xcd_phase_limit = value;
     else if (k == "xcd_force_global") c->xcd_force_global = value;
     else if (k == "face") c->face_on = value != 0;
@@ -2527,6 +2589,7 @@ int hd_get_option(hd_ctx* c, const char* key) {
     if (!c || !key) return HD_ERR_INVALID;
     const std::string k = key;
     if (k == "xcd") return (c->xcd_ok && c->xcd_on) ? 1 : 0;
+    if (k == "xcd2") return (c->xcd_ok && c->xcd_on && c->xcd2_on) ? c->xcd2_mask : 0;
     if (k == "xcd_stages") return (int)c->xstages.size();
     if (k == "face_stages") return (int)c->fstages.size();
     return HD_ERR_INVALID;

@@ -72,6 +72,7 @@ struct X2StageP {
     int phase_limit, force_global;
 #ifdef HD_STAMPS
     unsigned long long* stamps;            // [phase][workgroup][8] of compute wave 0
+    int dbg_no_w;                          // timing-only what-if (results are garbage): the loaders count their steps but move no weights
 #endif
 };
 

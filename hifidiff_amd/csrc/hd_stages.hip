@@ -2,12 +2,19 @@
 // (models/denoiser/conditional_naf.py:108-136) of one level as one launch.  Entry points: hd_stage_api.hpp.
 #include "hd_face.hpp"
 #include "hd_xcd.hpp"
+#include "hd_xcd2.hpp"
 
 namespace hd {
 
 hipError_t run_xcd_stage(int C, const XStageP& p, hipStream_t s) {
     if (C == 1024) return launch_xcd_stage<1024, 4>(p, s);
     if (C == 512) return launch_xcd_stage<512, 16>(p, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t run_xcd2_stage(int C, const X2StageP& p, hipStream_t s) {
+    if (C == 1024) return launch_xcd2_stage<1024, 4>(p, s);
+    if (C == 512) return launch_xcd2_stage<512, 16>(p, s);
     return hipErrorInvalidValue;
 }
 

@@ -50,12 +50,19 @@ struct X2Cfg {
     static constexpr int KSW = KS / KSPL;               // k-steps per wave: 16 / 16
     static constexpr int S = (HW == 4) ? 2 : 4;         // face side
     static constexpr int NCW = 4, NLW = 4, THREADS = 64 * (NCW + NLW);
-    static constexpr int RING = (C >= 1024) ? 128 : 64; // weight ring, 1 KiB fragments
+    static constexpr int RING = 128;                    // weight ring, 1 KiB fragments (level 3: one pair phase; level 2: two)
     static constexpr int GBF = 2 * C * 4 / 1024;        // fragments of a FiLM gain | bias row: 8 / 4
     static constexpr int DWF = 3;                       // fragments of the depthwise constants (704 floats)
     static constexpr int NPE = C / 32, NPS = C / 16;    // statistics partials per row: entry / inside the stage
-    static constexpr int DL = 8;                        // LDS-DMA instructions a loader wave keeps in flight
-    static constexpr int FLAGW = (KSPL == 2) ? 32 : 16; // flags a consumer wave polls
+#ifndef HD_X2_DL
+#define HD_X2_DL 8
+#endif
+#ifndef HD_X2_PD
+#define HD_X2_PD 2
+#endif
+    static constexpr int DL = HD_X2_DL;                 // LDS-DMA instructions a loader wave keeps in flight
+    static constexpr int FLAGW = (KSPL == 2) ? 64 : 16; // flags a consumer wave polls: every producer of its row block (level 3: both K halves --
+                                                        // the LayerNorm statistics of a row come from all 32 channel tiles)
     static_assert(RB * KSPL == 4 && KSW == 16 && (HW == 4 || HW == 16), "geometry");
 };
 
@@ -75,6 +82,8 @@ struct X2Lds {
 // s_waitcnt vmcnt(0) in front of every LDS access it can see (the DMA writes LDS), which would drain the ring.
 __device__ __forceinline__ unsigned x2_lds_addr(const void* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p; }
 __device__ __forceinline__ unsigned x2_lds_ld(unsigned addr) { unsigned v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory"); return v; }
+// the same for a control word every lane reads at one address: the value is wave-uniform, so are the branches on it
+__device__ __forceinline__ unsigned x2_lds_ldu(unsigned addr) { return __builtin_amdgcn_readfirstlane(x2_lds_ld(addr)); }
 __device__ __forceinline__ void x2_lds_st(unsigned addr, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void x2_dma(const void* src_lane, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)src_lane,
@@ -92,6 +101,14 @@ __device__ __forceinline__ float x2_sum_rows(float v) {
 template <int CTRL>
 __device__ __forceinline__ float x2_dpp0(float v) {      // DPP move, lanes without a source read 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// a wait gave up: the workgroup's abort word (every wave of it leaves), the device word the later stages of the call read, the host-visible word
+__device__ __forceinline__ void x2_give_up(unsigned a_abort, unsigned* abort_dev, unsigned* tmo, unsigned code, int lane) {
+    if (lane == 0) {
+        x2_lds_st(a_abort, 1u);
+        __hip_atomic_store((xs_gu32*)abort_dev, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((xs_gu32*)tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 __device__ __forceinline__ const uint4* x2_weights(const XBlockW& b, int q) { return q == 0 ? b.w1 : q == 1 ? b.wsca : q == 2 ? b.w3 : q == 3 ? b.w4 : b.w5; }
 
@@ -172,7 +189,7 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
                 for (unsigned spins = 0;; ++spins) {
                     const unsigned v = lane < K::NCW ? x2_lds_ld(a_gbdone + 4 * lane) : 0xffffffffu;
                     if (__all(v >= (unsigned)ln_seen)) break;
-                    if (x2_lds_ld(a_abort)) return;
+                    if (x2_lds_ldu(a_abort)) return;
                     if (spins > XS_SPINS) { x2_lds_st(a_abort, 1u); return; }
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -207,7 +224,11 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
                     for (unsigned spins = 0;; ++spins) {              // room in the ring: the slowest compute wave has let go of the fragments this step overwrites
                         const unsigned v = lane < K::NCW ? x2_lds_ld(a_cons + 4 * lane) : cum_e;
                         if (__all((int)(cum_e - v) <= K::RING)) break;
-                        if (x2_lds_ld(a_abort)) return;
+                        if (spins == 0) {                             // blocked anyway: everything issued so far lands and is reported
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (lane == 0) x2_lds_st(a_landed, issued);
+                        }
+                        if (x2_lds_ldu(a_abort)) return;
                         if (spins > XS_SPINS) { x2_lds_st(a_abort, 1u); return; }
                         __builtin_amdgcn_s_sleep(1);
                     }
@@ -216,11 +237,14 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
                         if (f < nf) {
                             const int h = f % nh, cb = (f / nh) & 1, kh = f / (2 * nh);
                             const int mb = (h ? C / 16 : 0) + ct * 2 + cb, ks = kh * 16 + j;
+#ifdef HD_STAMPS
+                            if (p.dbg_no_w) continue;
+#endif
                             x2_dma(W + ((size_t)mb * K::KS + ks) * 64 + lane, &L.ring[(cum + f) % K::RING][0]);
                         }
                     }
                     issued += nf;
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // = DL
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K::DL) : "memory");
                     if (issued > K::DL && lane == 0) x2_lds_st(a_landed, issued - K::DL);
                 }
                 cum += nf;
@@ -254,20 +278,15 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
     const __amdgpu_buffer_rsrc_t rs_Xb = __builtin_amdgcn_make_buffer_rsrc(p.Xb, 0, M * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.sx), 0, M * K::NPE * 8, 0x00020000);
 
-    // flags: level 3 [rb][ct][kh] (a consumer's 32 producers are contiguous), level 2 [row block of the group][ct]
+    // flags: level 3 [rb][ct][kh] (a consumer's 64 producers are contiguous: two lines), level 2 [row block of the group][ct]
     xs_gu32* fl_grp = (xs_gu32*)(p.flags + group * 128);
     xs_gu32* my_flag = fl_grp + (K::KSPL == 2 ? rb * 64 + ct * 2 + kh : rbg * 16 + ct);
-    xs_gu32* poll_base = fl_grp + (K::KSPL == 2 ? rb * 64 + kh * 32 : rbg * 16);
+    xs_gu32* poll_base = fl_grp + (K::KSPL == 2 ? rb * 64 : rbg * 16);
 
     bool dead = false;
-    auto give_up = [&](unsigned code) __attribute__((always_inline)) {
-        if (lane == 0) {
-            x2_lds_st(a_abort, 1u);
-            __hip_atomic_store((xs_gu32*)p.abort_dev, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store((xs_gu32*)p.tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        dead = true;
-    };
+    unsigned* const abort_dev = p.abort_dev;
+    unsigned* const tmo = p.tmo;
+#define X2_GIVE_UP(code) do { x2_give_up(a_abort, abort_dev, tmo, (code), lane); dead = true; } while (0)
     // wait until the producers of this wave's rows / k have published phase ph - 1
     auto wait_flags = [&](int ph) __attribute__((always_inline)) {
         const unsigned want = base + (unsigned)ph;
@@ -275,8 +294,8 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
             const unsigned v = lane < K::FLAGW ? __hip_atomic_load(poll_base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
             const bool inject = p.test_abort > 0 && ph == p.test_abort && group == 0;
             if (!inject && __all((int)(v - want) >= 0)) break;
-            if (x2_lds_ld(a_abort)) { dead = true; break; }
-            if (spins > XS_SPINS || inject) { give_up(0x100u + (unsigned)(ph - 1)); break; }
+            if (x2_lds_ldu(a_abort)) { dead = true; break; }
+            if (spins > XS_SPINS || inject) { X2_GIVE_UP(0x100u + (unsigned)(ph - 1)); break; }
             __builtin_amdgcn_s_sleep(1);
         }
     };
@@ -315,10 +334,10 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
     auto wait_landed = [&](int l, unsigned need, unsigned code) __attribute__((always_inline)) {
         if ((int)(lseen[l] - need) >= 0) return;
         for (unsigned spins = 0;; ++spins) {
-            lseen[l] = x2_lds_ld(a_landed0 + 4 * l);
+            lseen[l] = x2_lds_ldu(a_landed0 + 4 * l);
             if ((int)(lseen[l] - need) >= 0) break;
-            if (x2_lds_ld(a_abort)) { dead = true; break; }
-            if (spins > XS_SPINS) { give_up(code); break; }
+            if (x2_lds_ldu(a_abort)) { dead = true; break; }
+            if (spins > XS_SPINS) { X2_GIVE_UP(code); break; }
             __builtin_amdgcn_s_sleep(1);
         }
     };
@@ -352,55 +371,88 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
         nmr = -mean * rstd;
     };
 
-    // K loop of one phase: NH accumulators per channel block; LN: LayerNorm2d + FiLM on the way in
-    auto k_loop = [&](int ph, auto nh_c, auto ln_c) __attribute__((always_inline)) {
+    // LayerNorm2d + FiLM (utils.py:16-24, conditional_naf.py:114-115,126-127) applied to this wave's B operand in place, as the rows
+    // arrive (loads return in order) and before the K loop: a pass of LDS reads (gain | bias of the lane's 8 k per k-step) and packed
+    // VALU only, which the compiler is free to batch -- inside the K loop the same reads sat on the MFMA chain (4.7 us per phase)
+    auto ln_transform = [&](int ph) __attribute__((always_inline)) {
+        lcnt[0] += K::GBF + ((ph % 5) == 0 ? K::DWF : 0);
+        wait_landed(0, lcnt[0], 0x400u + (unsigned)ph);
+        asm volatile("" ::: "memory");
+        const f32x2_t rs2 = {rstd, rstd}, nm2 = {nmr, nmr};
+        // three k-steps of gain | bias reads in flight (the asm statements keep the compiler from batching all 64 reads in front of the
+        // arithmetic: 256 registers)
+        f32x4_t gq4[3][4];
+        typedef __attribute__((address_space(3))) const f32x4_t lds_f4;
+        unsigned gb_base = x2_lds_addr(L.gb) + (unsigned)(kh * 2048 + g * 32);
+        asm volatile("" : "+v"(gb_base));                                 // opaque: the 64 addresses below are base + immediate, not 64 hoisted registers
+#pragma unroll
+        for (int jj = 0; jj < 18; ++jj) {
+            if (jj < 16) {
+                const int bi = jj % 3;
+                gq4[bi][0] = *(lds_f4*)(gb_base + jj * 128); gq4[bi][1] = *(lds_f4*)(gb_base + jj * 128 + 16);
+                gq4[bi][2] = *(lds_f4*)(gb_base + C * 4 + jj * 128); gq4[bi][3] = *(lds_f4*)(gb_base + C * 4 + jj * 128 + 16);
+            }
+            if (jj >= 2) {
+                const int j = jj - 2, bi = j % 3;
+                const f32x4_t g0 = gq4[bi][0], g1 = gq4[bi][1], b0 = gq4[bi][2], b1 = gq4[bi][3];
+                const f32x2_t gg[4] = {{g0.x, g0.y}, {g0.z, g0.w}, {g1.x, g1.y}, {g1.z, g1.w}};
+                const f32x2_t bb[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
+                const unsigned w[4] = {araw[j].x, araw[j].y, araw[j].z, araw[j].w};
+                unsigned o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2_t x = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+                    o[i] = pack2(__builtin_elementwise_fma(__builtin_elementwise_fma(x, rs2, nm2), gg[i], bb[i]));
+                }
+                araw[j] = (xs_u32x4){o[0], o[1], o[2], o[3]};
+                asm volatile("" : "+v"(araw[j]) :: "memory");           // the transform of step j is done before the reads of step j + 3 go out
+            } else {
+                asm volatile("" ::: "memory");
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0) x2_lds_st(a_gbdone, (unsigned)(ph / 5) * 2u + ((ph % 5) == 3 ? 2u : 1u));      // the gain | bias row is free again
+    };
+    // K loop of one phase: NH accumulators per channel block.  Software pipeline, one k-step deep: the weight fragments of step
+    // j + 1 are read from the ring before the MFMAs of step j, into the other register set (the loop is fully unrolled: indices are
+    // constants).  The waits are the compiler's (exact lgkmcnt / vmcnt counts per use); a ring slot is let go once its step has been used.
+    auto k_loop = [&](int ph, auto nh_c) __attribute__((always_inline)) {
         constexpr int NH = decltype(nh_c)::value;
-        constexpr bool LN = decltype(ln_c)::value;
         constexpr int NF = 2 * K::KSPL * NH;
+        constexpr int PD = HD_X2_PD;                                   // k-steps of ring reads in flight ahead of the MFMAs
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int h = 0; h < 2; ++h) acc[cb][h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (LN) { lcnt[0] += K::GBF + ((ph % 5) == 0 ? K::DWF : 0); wait_landed(0, lcnt[0], 0x400u + (unsigned)ph); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the activations (and statistics) of this phase
+        xs_u32x4 wf[PD + 1][2][NH];
+        typedef __attribute__((address_space(3))) const xs_u32x4 lds_u4;
+        const unsigned ring_lane = x2_lds_addr(&L.ring[0][0]) + (unsigned)lane * 16u;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            constexpr int dummy = 0; (void)dummy;
-            const int l = j & (K::NLW - 1);
-            lcnt[l] += NF;
-            wait_landed(l, lcnt[l], 0x500u + (unsigned)ph);
-            asm volatile("" ::: "memory");
-            uint4 wf[2][NH];
+        for (int jj = 0; jj < 16 + PD; ++jj) {
+            if (jj < 16) {
+                const int l = jj & (K::NLW - 1), bi = jj % (PD + 1);
+                lcnt[l] += NF;
+                wait_landed(l, lcnt[l], 0x500u + (unsigned)ph);
+                asm volatile("" ::: "memory");
+                // a step's fragments sit in consecutive slots (cum is a multiple of 32, a step of NF <= 8): one address per step
+                const unsigned step_addr = ring_lane + (((cum + (unsigned)(jj * NF)) % K::RING) << 10) + (unsigned)(kh * 2 * NH * 1024);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int h = 0; h < NH; ++h) wf[cb][h] = L.ring[(cum + (unsigned)((kh * 2 + cb) * NH + h)) % K::RING][lane];
-            xs_u32x4 a = araw[j];
-            if (LN) {
-                const int k = (kh * 16 + j) * 32 + 8 * g;
-                const float4 g0 = *reinterpret_cast<const float4*>(&L.gb[k]), g1 = *reinterpret_cast<const float4*>(&L.gb[k + 4]);
-                const float4 b0 = *reinterpret_cast<const float4*>(&L.gb[C + k]), b1 = *reinterpret_cast<const float4*>(&L.gb[C + k + 4]);
-                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                const unsigned w[4] = {a.x, a.y, a.z, a.w};
-                unsigned o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
-                    o[i] = pack2(fmaf(fmaf(x0, rstd, nmr), gg[2 * i], bb[2 * i]), fmaf(fmaf(x1, rstd, nmr), gg[2 * i + 1], bb[2 * i + 1]));
-                }
-                a = (xs_u32x4){o[0], o[1], o[2], o[3]};
+                    for (int h = 0; h < NH; ++h) wf[bi][cb][h] = *(lds_u4*)(step_addr + (cb * NH + h) * 1024);
             }
-            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
+            if (jj >= PD) {
+                const int j = jj - PD, bi = j % (PD + 1);
+                const bf16x8_t av = __builtin_bit_cast(bf16x8_t, araw[j]);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int h = 0; h < NH; ++h)
-                    acc[cb][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[cb][h]), av, acc[cb][h], 0, 0, 0);
-            cum += NF;
-            if ((j & 3) == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) x2_lds_st(a_cons, cum); }
+                    for (int h = 0; h < NH; ++h)
+                        acc[cb][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[bi][cb][h]), av, acc[cb][h], 0, 0, 0);
+                if ((j & 1) && lane == 0) x2_lds_st(a_cons, cum + (unsigned)((j + 1) * NF));   // steps <= j are in registers: their slots are free
+            }
         }
-        if (LN && lane == 0) x2_lds_st(a_gbdone, (unsigned)(ph / 5) * 2u + ((ph % 5) == 3 ? 2u : 1u));
+        cum += 16 * NF;
     };
 
     // level 3: the two K halves of a row block swap the partial tiles of the rows the OTHER one finishes
@@ -423,9 +475,9 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
             if (lane == 0) x2_lds_st(x2_lds_addr(&L.xflag[cw]), (unsigned)ph + 1u);
             const unsigned a_their = x2_lds_addr(&L.xflag[cw ^ K::RB]);
             for (unsigned spins = 0;; ++spins) {
-                if ((int)(x2_lds_ld(a_their) - ((unsigned)ph + 1u)) >= 0) break;
-                if (x2_lds_ld(a_abort)) { dead = true; break; }
-                if (spins > XS_SPINS) { give_up(0x600u + (unsigned)ph); break; }
+                if ((int)(x2_lds_ldu(a_their) - ((unsigned)ph + 1u)) >= 0) break;
+                if (x2_lds_ldu(a_abort)) { dead = true; break; }
+                if (spins > XS_SPINS) { X2_GIVE_UP(0x600u + (unsigned)ph); break; }
             }
             asm volatile("" ::: "memory");
             if (own) {
@@ -440,9 +492,10 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
     };
 
     // activations of a phase from a hand-off buffer (fragment order, sc1) -- 16 KiB per wave
+    const int a_frag_off = ((grb * K::KS + kh * 16) * 64 + lane) * 16;
     auto load_a = [&](const __amdgpu_buffer_rsrc_t& rs) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) araw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((grb * K::KS + kh * 16 + j) * 64 + lane) * 16, 0, 16);
+        for (int j = 0; j < 16; ++j) araw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_frag_off, j * 1024, 16);
     };
     // (row, 16 channels) statistics of the finished tile -> hand-off, one 16-byte store per row (both channel blocks)
     auto store_stats = [&](const __amdgpu_buffer_rsrc_t& rs, const float (&v)[2][4]) __attribute__((always_inline)) {
@@ -475,7 +528,7 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
                     ps[2 * i] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y)); ps[2 * i + 1] = make_float2(__uint_as_float(r.z), __uint_as_float(r.w));
                 }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) araw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_Xb, (rowc * C + (kh * 16 + j) * 32 + 8 * g) * 2, 0, 0);
+                for (int j = 0; j < 16; ++j) araw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_Xb, (rowc * C + kh * 512 + 8 * g) * 2, j * 64, 0);
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 merge_stats(ps, std::integral_constant<int, K::NPE / 4>(), 32.f);
             } else {
@@ -491,7 +544,10 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 merge_stats(ps, std::integral_constant<int, K::NPS / 4>(), 16.f);
             }
-            k_loop(ph, std::integral_constant<int, 2>(), std::true_type()); if (dead) break;
+            HD_X2STAMP(7);
+            ln_transform(ph); if (dead) break;
+            HD_X2STAMP(6);
+            k_loop(ph, std::integral_constant<int, 2>()); if (dead) break;
             HD_X2STAMP(2);
             exchange(ph, std::integral_constant<int, 2>()); if (dead) break;
             HD_X2STAMP(3);
@@ -526,17 +582,26 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
                         // 4 x 4 face = one 16-lane row: pixel n = 4 y + x; x neighbours masked at the image border, y neighbours
                         // through row_shr:4 / row_shl:4, which read 0 outside the row (= outside the face)
                         const int px = n & 3;
+                        float tapw[9][4];
+#pragma unroll
+                        for (int t9 = 0; t9 < 9; ++t9) {
+                            const float4 w = *reinterpret_cast<const float4*>(&L.dwc[(h * 9 + t9) * 32 + 16 * cb + cc]);
+                            tapw[t9][0] = w.x; tapw[t9][1] = w.y; tapw[t9][2] = w.z; tapw[t9][3] = w.w;
+                        }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const float lft = px > 0 ? x2_dpp0<0x111>(t[i]) : 0.f;        // row_shr:1 -> value of pixel n - 1
-                            const float rgt = px < 3 ? x2_dpp0<0x101>(t[i]) : 0.f;        // row_shl:1 -> value of pixel n + 1
+                            // (the DPP moves are executed by every lane, THEN masked: inside a conditional the source lanes of the
+                            // lanes that take it would be switched off and read as 0)
+                            const float l1 = x2_dpp0<0x111>(t[i]), r1 = x2_dpp0<0x101>(t[i]);   // row_shr:1 / row_shl:1 -> value of pixel n - 1 / n + 1
+                            const float lft = px > 0 ? l1 : 0.f;
+                            const float rgt = px < 3 ? r1 : 0.f;
                             const float xs3[3] = {lft, t[i], rgt};
 #pragma unroll
                             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                                 for (int dx = 0; dx < 3; ++dx) {
                                     const float v = dy == 0 ? x2_dpp0<0x114>(xs3[dx]) : dy == 2 ? x2_dpp0<0x104>(xs3[dx]) : xs3[dx];   // row above: n - 4, below: n + 4
-                                    o[i] = fmaf(L.dwc[(h * 9 + dy * 3 + dx) * 32 + 16 * cb + cc + i], v, o[i]);
+                                    o[i] = fmaf(tapw[dy * 3 + dx][i], v, o[i]);
                                 }
                         }
                     }
@@ -577,9 +642,9 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
             HD_X2STAMP(1);
             // the pooled vector of this row's face, as if it were the row: s then lands in the lane that holds g
 #pragma unroll
-            for (int j = 0; j < 16; ++j) araw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_P16, (face * C + (kh * 16 + j) * 32 + 8 * g) * 2, 0, 16);
+            for (int j = 0; j < 16; ++j) araw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_P16, (face * C + kh * 512 + 8 * g) * 2, j * 64, 16);
             const float4 bs0 = col4(B.bsca, 0), bs1 = col4(B.bsca, 1);
-            k_loop(ph, std::integral_constant<int, 1>(), std::false_type()); if (dead) break;
+            k_loop(ph, std::integral_constant<int, 1>()); if (dead) break;
             HD_X2STAMP(2);
             exchange(ph, std::integral_constant<int, 1>()); if (dead) break;
             HD_X2STAMP(3);
@@ -610,7 +675,7 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
             HD_X2STAMP(1);
             load_a(rs_hG);
             const float4 c0 = col4(B.b3, 0), c1 = col4(B.b3, 1), e0 = col4(B.beta, 0), e1 = col4(B.beta, 1);
-            k_loop(ph, std::integral_constant<int, 1>(), std::false_type()); if (dead) break;
+            k_loop(ph, std::integral_constant<int, 1>()); if (dead) break;
             HD_X2STAMP(2);
             exchange(ph, std::integral_constant<int, 1>()); if (dead) break;
             HD_X2STAMP(3);
@@ -646,7 +711,10 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
             const float4 a0 = col4(B.b4, 0), a1 = col4(B.b4, 1), d0 = col4(B.b4 + C, 0), d1 = col4(B.b4 + C, 1);
             asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
             merge_stats(ps, std::integral_constant<int, K::NPS / 4>(), 16.f);
-            k_loop(ph, std::integral_constant<int, 2>(), std::true_type()); if (dead) break;
+            HD_X2STAMP(7);
+            ln_transform(ph); if (dead) break;
+            HD_X2STAMP(6);
+            k_loop(ph, std::integral_constant<int, 2>()); if (dead) break;
             HD_X2STAMP(2);
             exchange(ph, std::integral_constant<int, 2>()); if (dead) break;
             HD_X2STAMP(3);
@@ -674,7 +742,7 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
             HD_X2STAMP(1);
             load_a(rs_hG);
             const float4 c0 = col4(B.b5, 0), c1 = col4(B.b5, 1), e0 = col4(B.gamma, 0), e1 = col4(B.gamma, 1);
-            k_loop(ph, std::integral_constant<int, 1>(), std::false_type()); if (dead) break;
+            k_loop(ph, std::integral_constant<int, 1>()); if (dead) break;
             HD_X2STAMP(2);
             exchange(ph, std::integral_constant<int, 1>()); if (dead) break;
             HD_X2STAMP(3);

@@ -662,6 +662,7 @@ def test_xcd_stages_match_the_per_gemm_launches_bit_for_bit(gpu, weights16):
     from hifidiff_amd import _lib, sampling, schedulers, synth
     L = _lib.lib()
     m = make_model(weights16)
+    _opt(m, "xcd2", 0)                                                  # this test: hd_xcd.hpp at both levels (level 2 runs hd_xcd2.hpp by default)
     for B in (64, 13, 5):
         x, crl, crf = [t.cuda() for t in synth.sample_inputs(B, 16)]
         _opt(m, "xcd", 1)
@@ -697,6 +698,47 @@ def test_xcd_stages_match_the_per_gemm_launches_bit_for_bit(gpu, weights16):
     _opt(m, "xcd", 0)
     assert rel_l2(e1.cpu(), m(x, 500, crf, crl).sample.cpu()) <= 4e-3
     _opt(m, "xcd", 1)
+
+
+def test_autonomous_wave_stages_against_launches_and_oracle(gpu, weights16):
+    """hd_xcd2.hpp (the form level 2 runs by default; HD_XCD2=3 at creation builds it for level 3 as well): 16x16x32 MFMAs with
+    the weights as the A operand, per-wave hand-offs, weights through an LDS ring.  One K chain per 512 channels instead of
+    eight K slices, so it agrees with the per-GEMM launches to accumulation order (eps rel-L2 <= 3e-3 at batch 64, 13, 5),
+    bit for bit with itself (replays, the placement-independent hand-off form, 30 graph-replayed DDPM steps), and every
+    block of its stages with the oracle on the block's own input (conditional_naf.py:108-136) at both levels."""
+    import op_forced
+    from hifidiff_amd import _lib, sampling, schedulers, synth
+    L = _lib.lib()
+    os.environ["HD_XCD2"] = "3"
+    try:
+        m = make_model(weights16)
+        x, crl, crf = [t.cuda() for t in synth.sample_inputs(64, 16)]
+        m(x, 500, crf, crl)                                              # finalizes the context under the variable
+    finally:
+        del os.environ["HD_XCD2"]
+    assert L.hd_get_option(m.engine.ctx, b"xcd2") == 3
+    for B in (64, 13, 5):
+        x, crl, crf = [t.cuda() for t in synth.sample_inputs(B, 16)]
+        _opt(m, "xcd2", 1)
+        e2 = m(x, 500, crf, crl).sample.clone()
+        assert torch.equal(m(x, 500, crf, crl).sample, e2)              # reproducible
+        _opt(m, "xcd_force_global", 1)
+        assert torch.equal(m(x, 500, crf, crl).sample, e2)              # write-through hand-offs: the same bits
+        _opt(m, "xcd_force_global", 0)
+        _opt(m, "xcd", 0)
+        e0 = m(x, 500, crf, crl).sample.clone()
+        _opt(m, "xcd", 1)
+        assert bool(torch.isfinite(e2).all()) and rel_l2(e2.cpu(), e0.cpu()) <= 3e-3, (B, rel_l2(e2.cpu(), e0.cpu()))
+    sch = schedulers.DDPMScheduler(clip_sample_range=3.0)
+    sch.timesteps = sch.timesteps[:30]
+    a = sampling.sample(m, x, crf, crl, sch, seed=3, check=True)
+    assert torch.equal(a, sampling.sample(m, x, crf, crl, sch, seed=3, check=True))
+    for B in (2, 64):
+        xs, cl, cf = synth.sample_inputs(B, 16)
+        rep = []
+        worst = op_forced.stage_forced_scan(m, weights16, xs, cl, cf, 500.0, rep)
+        assert worst["stages"] == 8 and not [r for r in rep if "<<<<<<" in r], [r for r in rep if "<<<<<<" in r][:8]
+        assert worst["fp32"] <= 3e-4 and worst["bf16"] <= 3e-3, (B, worst)
 
 
 def test_parked_graphs_follow_a_moved_coefficient_buffer(gpu, weights16):
