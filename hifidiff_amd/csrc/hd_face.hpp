@@ -32,24 +32,30 @@ namespace hd {
 #define HD_FSTAMP(i) do { } while (0)
 #endif
 
-template <int C>
+// OWN = pixel rows a workgroup owns: 32 (level 0: 2 image rows of 16, 512 workgroups at two per CU; level 1 in its first form:
+// 4 image rows of 8, 128 workgroups = half the chip) or 16 (level 1: 2 image rows, 256 workgroups = every CU; own + halo rows
+// are then exactly one 32-row MFMA tile, the GEMMs after the depthwise stage use half of theirs)
+template <int C, int OWN_ = 32>
 struct FaceCfg {
     static constexpr int S = (C == 128) ? 16 : 8;              // face side
-    static constexpr int HW = S * S, CL = HW / 32, RI = 32 / S;   // pixels per face, workgroups per face, image rows per workgroup
+    static constexpr int OWN = OWN_;
+    static constexpr int HW = S * S, CL = HW / OWN, RI = OWN / S;   // pixels per face, workgroups per face, image rows per workgroup
     static constexpr int NT = C / 32, THREADS = 64 * NT, KS = C / 16;
+    static constexpr int ROWS = OWN + 2 * S, MT1 = (ROWS + 31) / 32;   // own + halo rows; 32-row MFMA tiles of conv1
     static constexpr int AROW = C * 2 + 16;                    // bytes per bf16 tile row (padded)
     static constexpr int XROW = C + 4;                         // floats per fp32 tile row (padded)
-    static constexpr int XT_OFF = 0;                           // x / y / x' tile fp32 [32][XROW]
-    static constexpr int ALN_OFF = XT_OFF + 32 * XROW * 4;     // LayerNorm output bf16 [64][AROW]: rows 0..31 own, 32.. above halo, 32+S.. below
-    static constexpr int A1_OFF = ALN_OFF + 32 * AROW;         // gate tile bf16 [32][AROW]: rows 32..63 of the LN tile (the halo rows are dead once
-                                                               // conv1 has run; a barrier separates the two uses) -> two workgroups per CU at C = 128
-    static constexpr int T1_OFF = ALN_OFF + 64 * AROW;         // per wave: conv1 half tile fp32 [64][32]
-    static constexpr int SV_OFF = T1_OFF + NT * 64 * 32 * 4;   // sca vector [C]
+    static constexpr int XT_OFF = 0;                           // x / y / x' tile fp32 [OWN][XROW]
+    static constexpr int ALN_OFF = XT_OFF + OWN * XROW * 4;    // LayerNorm output bf16 [MT1 * 32][AROW]: rows 0..OWN-1 own, OWN.. above halo, OWN+S.. below
+    // gate tile bf16 [32][AROW].  OWN = 32: rows 32..63 of the LN tile (the halo rows are dead once conv1 has run; a barrier separates
+    // the two uses) -> two workgroups per CU at C = 128.  OWN = 16: the LN tile is one MFMA tile, the gate tile gets its own
+    static constexpr int A1_OFF = ALN_OFF + 32 * AROW;
+    static constexpr int T1_OFF = ALN_OFF + 64 * AROW;         // per wave: conv1 half tile fp32 [MT1 * 32][32]
+    static constexpr int SV_OFF = T1_OFF + NT * MT1 * 32 * 32 * 4;   // sca vector [C]
     static constexpr int GB_OFF = SV_OFF + C * 4;              // FiLM gain | bias of norm1 and norm2 [4][C]
     static constexpr int PL_OFF = GB_OFF + 4 * C * 4;          // pooled mean [C]
     static constexpr int PP_OFF = PL_OFF + C * 4;              // this workgroup's channel sums [C]
     static constexpr int SMEM = PP_OFF + C * 4;
-    static_assert(32 + 2 * S <= 64, "own + halo rows fit two MFMA row tiles");
+    static_assert(ROWS <= 64 && (OWN == 32 || OWN == 16) && RI >= 2 && RI % 2 == 0, "own + halo rows fit two MFMA row tiles; two lane halves share the image rows");
 };
 
 typedef __attribute__((address_space(1))) unsigned fs_gu32;
@@ -62,9 +68,9 @@ __device__ __forceinline__ void face_load_b(const uint4* W, int tile, int lane, 
     for (int ks = 0; ks < C / 16; ++ks) b[ks] = xs_ldg_u4(Wl + ks * 64);
 }
 
-template <int C>
-__global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kernel(const FStageP p) {      // two waves per SIMD: two 4-wave workgroups per CU at C = 128
-    typedef FaceCfg<C> K;
+template <int C, int OWN = 32>
+__global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_kernel(const FStageP p) {      // two waves per SIMD: two 4-wave workgroups per CU at C = 128
+    typedef FaceCfg<C, OWN> K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ XBlockW s_blk[XS_MAXBLK];
     __shared__ unsigned s_abort, s_base;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
     const int face = xcd * 8 + fl;
     if (face >= p.B) return;                                        // nobody of this face takes part
     const int M = p.B * K::HW;
-    const int row0 = face * K::HW + kk * 32;                        // own rows
+    const int row0 = face * K::HW + kk * OWN;                       // own rows
     const bool has_up = kk > 0, has_dn = kk < K::CL - 1;
     const int tile = wave, col = tile * 32 + (lane & 31);
     float* xt = reinterpret_cast<float*>(smem + K::XT_OFF);
@@ -82,7 +88,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
     float* gb = reinterpret_cast<float*>(smem + K::GB_OFF);
     float* pooled = reinterpret_cast<float*>(smem + K::PL_OFF);
     float* poolp = reinterpret_cast<float*>(smem + K::PP_OFF);
-    float* t1w = reinterpret_cast<float*>(smem + K::T1_OFF) + wave * 64 * 32;
+    float* t1w = reinterpret_cast<float*>(smem + K::T1_OFF) + wave * K::MT1 * 32 * 32;
 
     {
         const unsigned* src = reinterpret_cast<const unsigned*>(p.blocks);
@@ -98,7 +104,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
     fs_gu32* flags = (fs_gu32*)(p.flags + face * 16);
 
     // ---- entry: own rows of x (written by the previous launch) ----
-    for (int u = tid; u < 32 * (C / 4); u += K::THREADS) {
+    for (int u = tid; u < OWN * (C / 4); u += K::THREADS) {
         const int r = u / (C / 4), q = u - r * (C / 4);
         *reinterpret_cast<float4*>(xt + r * K::XROW + q * 4) = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + q * 4);
     }
@@ -210,16 +216,17 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
         if (s_abort) return;
         {
             const int l16 = lane & 15;
-            constexpr int ROWS = 32 + 2 * K::S;
-            constexpr int HRI = (ROWS - 32 + K::NT * 4 - 1) / (K::NT * 4);      // halo rows per 16-lane group
+            constexpr int ROWS = K::ROWS;
+            constexpr int HRI = (ROWS - OWN + K::NT * 4 - 1) / (K::NT * 4);      // halo rows per 16-lane group
+            constexpr int HSH = (K::NT * 4 - OWN % (K::NT * 4)) % (K::NT * 4);   // OWN = 16 at 8 waves: waves 0..3 take the own rows, 4..7 the halo rows
             float4 hv[HRI][V4];
             bool hok[HRI];
 #pragma unroll
             for (int hi = 0; hi < HRI; ++hi) {                           // requested first: they arrive while the own rows are normalised
-                const int r = 32 + hi * K::NT * 4 + wave * 4 + (lane >> 4);
-                const bool up = r < 32 + K::S;
+                const int r = OWN + hi * K::NT * 4 + (wave * 4 + (lane >> 4) + HSH) % (K::NT * 4);
+                const bool up = r < OWN + K::S;
                 hok[hi] = r < ROWS && (up ? has_up : has_dn);
-                const int grow = up ? row0 - K::S + (r - 32) : row0 + 32 + (r - 32 - K::S);
+                const int grow = up ? row0 - K::S + (r - OWN) : row0 + OWN + (r - OWN - K::S);
                 const int gr = hok[hi] ? grow : row0;
 #pragma unroll
                 for (int i = 0; i < V4; ++i) {
@@ -227,7 +234,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
                     hv[hi][i] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
                 }
             }
-            for (int r = wave * 4 + (lane >> 4); r < 32; r += K::NT * 4) {
+            for (int r = wave * 4 + (lane >> 4); r < OWN; r += K::NT * 4) {
                 float4 v[V4];
 #pragma unroll
                 for (int i = 0; i < V4; ++i) v[i] = *reinterpret_cast<const float4*>(xt + r * K::XROW + 4 * l16 + 64 * i);
@@ -235,17 +242,17 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
             }
 #pragma unroll
             for (int hi = 0; hi < HRI; ++hi) {
-                const int r = 32 + hi * K::NT * 4 + wave * 4 + (lane >> 4);
+                const int r = OWN + hi * K::NT * 4 + (wave * 4 + (lane >> 4) + HSH) % (K::NT * 4);
                 if (r < ROWS) ln_row(hv[hi], gb + C, gb, smem + K::ALN_OFF + r * K::AROW, hok[hi]);
             }
         }
         __syncthreads();
         HD_FSTAMP(1);
         // ---- conv1 on own + halo rows: column tile j and j + C/32 (the two SimpleGate halves) ----
-        f32x16_t acc_a[2], acc_b[2];
-        chain_mma<C, 2>(smem + K::ALN_OFF, bw, lane, acc_a);
+        f32x16_t acc_a[K::MT1], acc_b[K::MT1];
+        chain_mma<C, K::MT1>(smem + K::ALN_OFF, bw, lane, acc_a);
         if constexpr (kEarly) {
-            chain_mma<C, 2>(smem + K::ALN_OFF, bw2, lane, acc_b);
+            chain_mma<C, K::MT1>(smem + K::ALN_OFF, bw2, lane, acc_b);
             face_load_b<C>(B.wsca, tile, lane, bw);      // the next GEMMs' weights fly during the depthwise stage
             face_load_b<C>(B.w3, tile, lane, bw2);
         } else {
@@ -254,11 +261,12 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
         }
         // ---- depthwise 3x3 (pad 1) of the own rows, half by half through the wave's LDS tile; SimpleGate ----
         HD_FSTAMP(2);
-        float u1[16], u2[16];
-        auto dw_half = [&](const f32x16_t (&acc)[2], float bias1, const float (&w)[9], float bias2, float (&u)[16]) __attribute__((always_inline)) {
+        constexpr int NU = (K::RI / 2) * K::S;                       // gate values per lane: image rows per lane half x face side
+        float u1[NU], u2[NU];
+        auto dw_half = [&](const f32x16_t (&acc)[K::MT1], float bias1, const float (&w)[9], float bias2, float (&u)[NU]) __attribute__((always_inline)) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < K::MT1; ++mt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int r = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
@@ -276,7 +284,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
                 for (int rr = 0; rr < 3; ++rr) { v[rr][0] = 0.f; v[rr][S + 1] = 0.f; }
                 const bool up_in = ir > 0, dn_in = ir < K::RI - 1;
                 const bool up_ok = up_in || has_up, dn_ok = dn_in || has_dn;
-                const int up_base = up_in ? (ir - 1) * S : 32, dn_base = dn_in ? (ir + 1) * S : 32 + S;
+                const int up_base = up_in ? (ir - 1) * S : OWN, dn_base = dn_in ? (ir + 1) * S : OWN + S;
 #pragma unroll
                 for (int x = 0; x < S; ++x) {
                     v[0][x + 1] = up_ok ? t1w[(up_base + x) * 32 + j] : 0.f;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
         };
         dw_half(acc_a, c_b1a, dwa, dba, u1);
         if constexpr (!kEarly) {
-            chain_mma<C, 2>(smem + K::ALN_OFF, bw, lane, acc_b);
+            chain_mma<C, K::MT1>(smem + K::ALN_OFF, bw, lane, acc_b);
             face_load_b<C>(B.wsca, tile, lane, bw);                  // conv3's weights follow after the depthwise pass (registers)
         }
         dw_half(acc_b, c_b1b, dwb, dbb, u2);
@@ -361,7 +369,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
         face_load_b<C>(B.w4, tile, lane, bw);
         __syncthreads();
         // ---- A1 <- bf16(bf16(g) * s) in place ----
-        for (int u = tid; u < 32 * (C / 8); u += K::THREADS) {
+        for (int u = tid; u < OWN * (C / 8); u += K::THREADS) {
             const int r = u / (C / 8), q = u - r * (C / 8);
             uint4* gp = reinterpret_cast<uint4*>(smem + K::A1_OFF + r * K::AROW + q * 16);
             float v[8];
@@ -377,7 +385,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
             chain_mma<C, 1>(smem + K::A1_OFF, bw2, lane, acc);
             face_load_b<C>(B.w4, tile + K::NT, lane, bw2);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < OWN / 2; ++i) {                           // tile rows (i & 3) + 8 (i >> 2) + 4 (lane >> 5) < OWN
                 const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 xt[r * K::XROW + col] = xt[r * K::XROW + col] + (acc[0][i] + c_b3) * c_beta;
             }
@@ -386,7 +394,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
         // ---- LayerNorm + FiLM on y -> rows 0..31 of the LN tile ----
         {
             const int l16 = lane & 15;
-            for (int r = wave * 4 + (lane >> 4); r < 32; r += K::NT * 4) {
+            for (int r = wave * 4 + (lane >> 4); r < OWN; r += K::NT * 4) {
                 float4 v[V4];
 #pragma unroll
                 for (int i = 0; i < V4; ++i) v[i] = *reinterpret_cast<const float4*>(xt + r * K::XROW + 4 * l16 + 64 * i);
@@ -401,7 +409,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
             chain_mma<C, 1>(smem + K::ALN_OFF, bw2, lane, a2);
             face_load_b<C>(B.w5, tile, lane, bw);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < OWN / 2; ++i) {
                 const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 *reinterpret_cast<unsigned short*>(smem + K::A1_OFF + r * K::AROW + col * 2) = f32_to_bf16_bits((a1[0][i] + c_b4a) * (a2[0][i] + c_b4b));
             }
@@ -412,7 +420,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
             f32x16_t acc[1];
             chain_mma<C, 1>(smem + K::A1_OFF, bw, lane, acc);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < OWN / 2; ++i) {
                 const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 xt[r * K::XROW + col] = xt[r * K::XROW + col] + (acc[0][i] + c_b5) * c_gamma;
             }
@@ -421,7 +429,7 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
         HD_FSTAMP(5);
         // ---- x' leaves: fp32 rows for the neighbours' halo (and the next launch); at the end of the run the bf16 / gated copies ----
         const bool last = blk == nb_run - 1;
-        for (int u = tid; u < 32 * (C / 8); u += K::THREADS) {
+        for (int u = tid; u < OWN * (C / 8); u += K::THREADS) {
             const int r = u / (C / 8), q = u - r * (C / 8);
             const float* xv = xt + r * K::XROW + q * 8;
             const float4 a = *reinterpret_cast<const float4*>(xv), b = *reinterpret_cast<const float4*>(xv + 4);
@@ -448,13 +456,13 @@ __global__ __launch_bounds__((FaceCfg<C>::THREADS), 2) void naf_face_stage_kerne
     if (kk == 0 && tid == 0) __hip_atomic_store((fs_gu32*)(p.gstate + face * 16), base / 64u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int C>
+template <int C, int OWN = 32>
 inline hipError_t launch_face_stage(const FStageP& p, hipStream_t s) {
-    typedef FaceCfg<C> K;
+    typedef FaceCfg<C, OWN> K;
     if (p.B < 1 || p.B > 64 || p.nblocks < 1 || p.nblocks > XS_MAXBLK) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> granted{0};
-        { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&naf_face_stage_kernel<C>), K::SMEM, granted); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL((naf_face_stage_kernel<C>), dim3(64 * K::CL), dim3(K::THREADS), K::SMEM, s, p);
+        { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&naf_face_stage_kernel<C, OWN>), K::SMEM, granted); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL((naf_face_stage_kernel<C, OWN>), dim3(64 * K::CL), dim3(K::THREADS), K::SMEM, s, p);
     return hipGetLastError();
 }
 

@@ -228,6 +228,7 @@ struct hd_ctx {
     bool face_ok = false;                     // decided per context in setup_xcd (HD_NO_FACE / HD_NO_XCD at the time the context is finalized)
     bool face_on = true;                      // run-time switch (hd_set_option "face")
     int face_block_limit = 0;
+    int face_l1_rows = 16;                    // pixel rows per workgroup of the level-1 stage: 16 = 256 workgroups (every CU), 32 = 128 (HD_FACE_L1_ROWS, experiments)
     int stage_limit_first = -1;               // introspection: the limits above apply only to the stage whose first block has this index (< 0: to all)
     unsigned* xcd_tmo_host = nullptr;         // pinned, device-mapped: non-zero after a hand-off wait gave up
     unsigned* xcd_tmo_dev = nullptr;
@@ -1277,7 +1278,7 @@ int build_denoiser_program(hd_ctx* c) {
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
                 r.block_limit = (c->stage_limit_first < 0 || c->stage_limit_first == first) ? c->face_block_limit : 0;
                 r.test_abort = c->stage_test_abort;
-                const hipError_t e = run_face_stage(c128 ? 128 : 256, r, s);
+                const hipError_t e = run_face_stage(c128 ? 128 : 256, c128 ? 32 : c->face_l1_rows, r, s);
                 if (e == hipSuccess) return e;
                 (void)hipGetLastError();                      // (the dynamic-LDS grant was refused: nothing was launched) -> the per-block launches
                 c->face_on = false;
@@ -1792,7 +1793,8 @@ int setup_xcd(hd_ctx* c) {
     HIPCHECK(c, hipMemset(c->abort_dev, 0, 64 * sizeof(unsigned)));
     c->xcd_ok = true;
     c->xcd2_mask = getenv("HD_XCD2") ? (atoi(getenv("HD_XCD2")) & 3) : 1;
-    c->face_ok = getenv("HD_NO_FACE") == nullptr;        // per context, like xcd_ok: not a process-wide static (fixtures toggle the variable around make_model)
+    c->face_ok = getenv("HD_NO_FACE") == nullptr;
+    if (const char* e = getenv("HD_FACE_L1_ROWS")) c->face_l1_rows = atoi(e) == 32 ? 32 : 16;        // per context, like xcd_ok: not a process-wide static (fixtures toggle the variable around make_model)
     return HD_OK;
 }
 // the device-side description of a stage (weights only: shared by every workspace), created on first use

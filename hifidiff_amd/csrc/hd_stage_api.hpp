@@ -77,9 +77,9 @@ struct X2StageP {
 };
 
 // host entry points (hd_stages.hip).  C selects the instantiation: XCD-local stages 1024 (level 3, 2 x 2 faces) / 512 (level 2,
-// 4 x 4 faces); face-cluster stages 128 (level 0, 16 x 16 faces) / 256 (level 1, 8 x 8 faces).  hipErrorInvalidValue otherwise.
+// 4 x 4 faces); face-cluster stages 128 (level 0, 16 x 16 faces) / 256 (level 1, 8 x 8 faces: 16 rows per workgroup put it on all 256 CUs).  hipErrorInvalidValue otherwise.
 hipError_t run_xcd_stage(int C, const XStageP& p, hipStream_t s);
 hipError_t run_xcd2_stage(int C, const X2StageP& p, hipStream_t s);
-hipError_t run_face_stage(int C, const FStageP& p, hipStream_t s);
+hipError_t run_face_stage(int C, int own_rows, const FStageP& p, hipStream_t s);   // own_rows: pixel rows per workgroup, 32 (C = 128, 256) or 16 (C = 256)
 
 }  // namespace hd

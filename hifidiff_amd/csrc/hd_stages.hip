@@ -18,9 +18,10 @@ hipError_t run_xcd2_stage(int C, const X2StageP& p, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-hipError_t run_face_stage(int C, const FStageP& p, hipStream_t s) {
-    if (C == 128) return launch_face_stage<128>(p, s);
-    if (C == 256) return launch_face_stage<256>(p, s);
+hipError_t run_face_stage(int C, int own_rows, const FStageP& p, hipStream_t s) {
+    if (C == 128 && own_rows == 32) return launch_face_stage<128, 32>(p, s);
+    if (C == 256 && own_rows == 32) return launch_face_stage<256, 32>(p, s);
+    if (C == 256 && own_rows == 16) return launch_face_stage<256, 16>(p, s);
     return hipErrorInvalidValue;
 }
 

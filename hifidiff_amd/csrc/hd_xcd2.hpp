@@ -389,8 +389,8 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
         for (int jj = 0; jj < 18; ++jj) {
             if (jj < 16) {
                 const int bi = jj % 3;
-                gq4[bi][0] = *(lds_f4*)(gb_base + jj * 128); gq4[bi][1] = *(lds_f4*)(gb_base + jj * 128 + 16);
-                gq4[bi][2] = *(lds_f4*)(gb_base + C * 4 + jj * 128); gq4[bi][3] = *(lds_f4*)(gb_base + C * 4 + jj * 128 + 16);
+                gq4[bi][0] = *(lds_f4*)(size_t)(gb_base + jj * 128); gq4[bi][1] = *(lds_f4*)(size_t)(gb_base + jj * 128 + 16);
+                gq4[bi][2] = *(lds_f4*)(size_t)(gb_base + C * 4 + jj * 128); gq4[bi][3] = *(lds_f4*)(size_t)(gb_base + C * 4 + jj * 128 + 16);
             }
             if (jj >= 2) {
                 const int j = jj - 2, bi = j % 3;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) wf[bi][cb][h] = *(lds_u4*)(step_addr + (cb * NH + h) * 1024);
+                    for (int h = 0; h < NH; ++h) wf[bi][cb][h] = *(lds_u4*)(size_t)(step_addr + (cb * NH + h) * 1024);
             }
             if (jj >= PD) {
                 const int j = jj - PD, bi = j % (PD + 1);
