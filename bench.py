@@ -328,8 +328,9 @@ def main():
         flops_launch = SURVEY_FLOPS_PER_FACE_STEP.get(L, fl.value) * B
         tflops = flops_launch / step_s / 1e12 if step_s > 0 else 0.0
         traffic, traffic_src, measured_gbs = None, None, None
-        if os.path.exists(TRAFFIC_FILE) and B == 64 and world == 1:
-            tj = json.load(open(TRAFFIC_FILE))
+        tfile = TRAFFIC_FILE if a.latent == 16 else TRAFFIC_FILE.replace(".json", "_L%d.json" % a.latent)   # one file per latent
+        if os.path.exists(tfile) and B == 64 and world == 1:
+            tj = json.load(open(tfile))
             if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("latent") == a.latent and tj.get("kind") == a.kind:
                 traffic, traffic_src = tj["hbm_bytes_per_step"], tj["source"]
                 measured_gbs = round(traffic / step_s / 1e9, 1) if step_s > 0 else None

@@ -429,7 +429,10 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
         HD_FSTAMP(5);
         // ---- x' leaves: fp32 rows for the neighbours' halo (and the next launch); at the end of the run the bf16 / gated copies ----
         const bool last = blk == nb_run - 1;
-        for (int u = tid; u < OWN * (C / 8); u += K::THREADS) {
+        int row0e = row0, facee = face;                              // opaque here: the exit addresses are formed at the exit, not hoisted to the kernel's start and spilled
+        int tide = tid;
+        asm volatile("" : "+s"(row0e), "+s"(facee), "+v"(tide));
+        for (int u = tide; u < OWN * (C / 8); u += K::THREADS) {
             const int r = u / (C / 8), q = u - r * (C / 8);
             const float* xv = xt + r * K::XROW + q * 8;
             const float4 a = *reinterpret_cast<const float4*>(xv), b = *reinterpret_cast<const float4*>(xv + 4);
@@ -438,12 +441,12 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
             __builtin_amdgcn_raw_buffer_store_b128((xs_u32x4){__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)}, rs_X, off + 16, 0, 16);
             if (last) {
                 const float x8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                const size_t o = (size_t)(row0 + r) * C + q * 8;
+                const size_t o = (size_t)(row0e + r) * C + q * 8;
                 if (p.Xb) *reinterpret_cast<uint4*>(p.Xb + o) = pack8(x8);
                 if (p.outg16 && blk == p.nblocks - 1) {                // f_d * (1 + w_c + w_s): the HCA conv input (hca.py:28)
                     float gv[8];
-                    const float gsr = p.gate_s[row0 + r];
-                    const float* gc = p.gate_c + (size_t)face * C + q * 8;
+                    const float gsr = p.gate_s[row0e + r];
+                    const float* gc = p.gate_c + (size_t)facee * C + q * 8;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) gv[i] = x8[i] * (1.0f + gc[i] + gsr);
                     *reinterpret_cast<uint4*>(p.outg16 + o) = pack8(gv);

@@ -705,9 +705,12 @@ __global__ __launch_bounds__(XS_THREADS) void xcd_stage_kernel(const XStageP p) 
                 for (int r = lane; r < K::RCU; r += 64) if (row0 + r < M) st64(rs_sx, ((row0 + r) * K::NT + ct) * 8, st_out[r]);
             }
             if (last) {                                                   // exit: what the following launches read (kernel boundary)
-                if (tid < K::RCU * 4) {
-                    const int r = tid >> 2, q4 = tid & 3;
-                    const int row = row0 + r;
+                int row0e = row0;                                         // opaque here: the exit addresses are formed now, not hoisted to the kernel's start and spilled
+                int tide = tid;
+                asm volatile("" : "+s"(row0e), "+v"(tide));
+                if (tide < K::RCU * 4) {
+                    const int r = tide >> 2, q4 = tide & 3;
+                    const int row = row0e + r;
                     if (row < M) {
                         const float* xv = &L.xt[r * 32 + q4 * 8];
                         float* xo = p.X + (size_t)row * C + ct * 32 + q4 * 8;

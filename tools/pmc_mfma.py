@@ -15,9 +15,12 @@ import sys
 
 
 def family(k):
-    m = re.search(r"xcd_stage_kernel<(\d+), *(\d+)>", k)
+    m = re.search(r"xcd(2?)_stage_kernel<(\d+), *(\d+)>", k)
     if m:
-        return f"xcd_stage<{m.group(1)},{m.group(2)}> (levels 2/3, persistent)"
+        return f"xcd{m.group(1)}_stage<{m.group(2)},{m.group(3)}> (levels 2/3, persistent)"
+    m = re.search(r"naf_face_stage_kernel<(\d+), *(\d+)>", k)
+    if m:
+        return f"naf_face_stage<{m.group(1)},{m.group(2)}> (levels 0/1, persistent)"
     if "naf_chain_kernel" in k:
         return "naf_chain (levels 0/1)"
     if "hca_conv_kernel" in k:
