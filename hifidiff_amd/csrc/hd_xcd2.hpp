@@ -20,6 +20,10 @@
 //     (global_load_lds_dwordx4), throttled, independent of the phase structure; the FiLM gain / bias row of a LayerNorm
 //     and the depthwise constants arrive the same way.  Compute waves never hold a weight load in flight, so they can
 //     drain their stores, poll and load activations without queueing behind the weight stream.
+//   * LayerNorm + FiLM (conv1, conv4) is applied to the wave's B operand in a pass of its own, as the rows arrive and before
+//     the K loop (inside the K loop its gain / bias LDS reads sat in front of every MFMA group); the K loop reads the ring
+//     two k-steps ahead of the MFMAs.  Both are LDS-bandwidth bound: this form wins at level 2 and
+//     loses to hd_xcd.hpp at level 3, which is why the library runs it at level 2 only.
 // LayerNorm2d statistics (utils.py:16-24): producers emit fp32 (mean, M2) partials per (row, 16 channels), consumers
 // merge them (equal counts: exact two-sum decomposition, fixed order).  Rounding points are those of hd_xcd.hpp /
 // hd_gemm.hpp (bf16 operands, fp32 everything else); summation ORDER differs (one K chain per 512 channels instead of
@@ -85,9 +89,12 @@ __device__ __forceinline__ unsigned x2_lds_ld(unsigned addr) { unsigned v; asm v
 // the same for a control word every lane reads at one address: the value is wave-uniform, so are the branches on it
 __device__ __forceinline__ unsigned x2_lds_ldu(unsigned addr) { return __builtin_amdgcn_readfirstlane(x2_lds_ld(addr)); }
 __device__ __forceinline__ void x2_lds_st(unsigned addr, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+#ifndef HD_X2_AUX
+#define HD_X2_AUX 0                                     // cache policy of the weight DMA (2 = nt: measured, not used)
+#endif
 __device__ __forceinline__ void x2_dma(const void* src_lane, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)src_lane,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, HD_X2_AUX);
 }
 // sum over the four lanes that share lane & 15 (the four 16-lane rows of the wave): two VALU lane swaps, no LDS
 __device__ __forceinline__ float x2_sum_rows(float v) {
@@ -790,6 +797,8 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
         __hip_atomic_store(gs, base / 64u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
+#undef X2_GIVE_UP
 
 template <int C, int HW>
 inline hipError_t launch_xcd2_stage(const X2StageP& p, hipStream_t s) {

@@ -53,6 +53,7 @@ void run(int nblocks, int B, int reps) {
     p.flags = sync; p.gstate = sync + 64 * 16;
     unsigned* tmo_h; CK(hipHostMalloc(reinterpret_cast<void**>(&tmo_h), 64, hipHostMallocMapped)); tmo_h[0] = 0;
     CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&p.tmo), tmo_h, 0));
+    { unsigned* ab; CK(hipMalloc(&ab, 256)); CK(hipMemset(ab, 0, 256)); p.abort_dev = ab; }      // every stage launch reads the abort word at entry
     const int grid = 64 * K::CL;
     p.stamps = dmalloc<unsigned long long>((size_t)nblocks * grid * 8); CK(hipMemset(p.stamps, 0, (size_t)nblocks * grid * 8 * 8));
     hipStream_t st; CK(hipStreamCreate(&st));

@@ -61,6 +61,7 @@ void run(int nblocks, int B, int reps, int force_global, int no_a = 0, int no_w 
     p.flags = sync; p.hello = sync + 256; p.gstate = sync + 512;
     unsigned* tmo_h; CK(hipHostMalloc(reinterpret_cast<void**>(&tmo_h), 64, hipHostMallocMapped)); tmo_h[0] = 0;
     CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&p.tmo), tmo_h, 0));
+    { unsigned* ab; CK(hipMalloc(&ab, 256)); CK(hipMemset(ab, 0, 256)); p.abort_dev = ab; }      // every stage launch reads the abort word at entry
     p.force_global = force_global; p.dbg_no_a = no_a; p.dbg_no_w = no_w;
     const int P = 5 * nblocks;
     p.stamps = dmalloc<unsigned long long>((size_t)P * 256 * 8); CK(hipMemset(p.stamps, 0, (size_t)P * 256 * 8 * 8));
