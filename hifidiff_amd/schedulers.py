@@ -65,10 +65,17 @@ class _Base:
         raise NotImplementedError
 
     def coefficient_table(self):
-        """(timesteps [n] fp32, coef [n,7] fp32) for hd_sample: see hd_schedule in include/hifidiff_hip.h."""
-        ts = [int(t) for t in self.timesteps]
-        return (torch.tensor(ts, dtype=torch.float32),
-                torch.tensor([self._coef(t) for t in ts], dtype=torch.float32).reshape(len(ts), 7))
+        """(timesteps [n] fp32, coef [n,7] fp32) for hd_sample: see hd_schedule in include/hifidiff_hip.h.
+        The table depends on the schedule only (1000 x a dozen fp32 scalar operations in diffusers' order: 12 ms of host time),
+        so it is kept until the timesteps or the clipping change -- like the FiLM table of the schedule inside hd_sample."""
+        ts = self.timesteps.tolist()
+        key = (tuple(ts), self.num_inference_steps, self.clip_sample, self.clip_sample_range)
+        hit = getattr(self, "_coef_cache", None)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.tensor(ts, dtype=torch.float32),
+                   torch.tensor([self._coef(int(t)) for t in ts], dtype=torch.float32).reshape(len(ts), 7))
+            self._coef_cache = hit
+        return hit[1], hit[2]
 
     def _launch(self, eps, t, x, noise, seed, step):
         if not (x.is_cuda and eps.is_cuda):

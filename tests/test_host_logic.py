@@ -68,6 +68,14 @@ def test_scheduler_tables_match_oracle(kind):
     ts, coef = s.coefficient_table()
     assert [int(t) for t in ts] == o.timesteps
     assert torch.equal(coef, O.step_coefficients(o, kind))
+    # the table is kept per schedule (12 ms of host scalar arithmetic at 1000 steps): the same tensors until the schedule changes
+    ts2, coef2 = s.coefficient_table()
+    assert ts2 is ts and coef2 is coef
+    s.timesteps = s.timesteps[:7]; o.timesteps = o.timesteps[:7]
+    ts3, coef3 = s.coefficient_table()
+    assert ts3.numel() == 7 and torch.equal(coef3, O.step_coefficients(o, kind)) and torch.equal(coef3, coef[:7])
+    s.clip_sample_range = 1.0
+    assert float(s.coefficient_table()[1][0, 2]) == 1.0
     s250 = schedulers.DDIMScheduler(); s250.set_timesteps(250)
     assert [int(t) for t in s250.timesteps[:2]] == [996, 992]
     with pytest.raises(NotImplementedError):
