@@ -17,8 +17,8 @@ import torch  # noqa: F401  (load order matters, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhifidiff_hip.so")
 # translation units (compiled in parallel, one hipcc each) and the headers they include
-UNITS = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_stages.hip", "hd_dispatch_ln.hip", "hd_dispatch_lnface.hip", "hd_dispatch_bf16.hip", "hd_dispatch_misc.hip")]
-SOURCES = UNITS + [os.path.join(_HERE, "csrc", f) for f in ("hd_gemm.hpp", "hd_dispatch.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_vae.hpp", "hd_stage_api.hpp", "hd_xcd.hpp", "hd_xcd2.hpp", "hd_face.hpp")]
+UNITS = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_aux.hip", "hd_stages.hip", "hd_dispatch_ln.hip", "hd_dispatch_lnface.hip", "hd_dispatch_bf16.hip", "hd_dispatch_misc.hip")]
+SOURCES = UNITS + [os.path.join(_HERE, "csrc", f) for f in ("hd_gemm.hpp", "hd_dispatch.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_vae.hpp", "hd_internal.hpp", "hd_stage_api.hpp", "hd_xcd.hpp", "hd_xcd2.hpp", "hd_face.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
 
 
@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-function"]
     objdir = os.path.join(_HERE, "csrc", "build")
     os.makedirs(objdir, exist_ok=True)
     objs = [os.path.join(objdir, os.path.splitext(os.path.basename(u))[0] + ".o") for u in UNITS]

@@ -10,7 +10,7 @@ namespace hd {
 
 // intro: Conv2d(3, 32, 3, pad 1) on the NCHW image -> channels-last fp32 + bf16 copy + LayerNorm partial (1 x 32).
 // 32 lanes = the 32 output channels of one pixel.
-__global__ __launch_bounds__(256) void cr_intro_kernel(const float* __restrict__ img, const float* __restrict__ w,
+static __global__ __launch_bounds__(256) void cr_intro_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ out,
                                                         unsigned short* __restrict__ out16, float2* __restrict__ stats, int B, int H) {
     const int co = threadIdx.x & 31;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void cr_intro_kernel(const float* __restrict__
 }
 
 // outro: Conv2d(32, 3, 3, pad 1) channels-last fp32 -> NCHW image.  One thread per output pixel.
-__global__ __launch_bounds__(256) void cr_outro_kernel(const float* __restrict__ X, const float* __restrict__ w,
+static __global__ __launch_bounds__(256) void cr_outro_kernel(const float* __restrict__ X, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ out, int B, int H) {
     __shared__ float wt[9][3][32];                                // [tap][co][ci]
     for (int i = threadIdx.x; i < 3 * 32 * 9; i += 256) {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void stn_conv_pool_relu_kernel(const StnConvP 
 }
 
 // fc_loc: theta = W2 relu(W1 xs + b1) + b2 (stn.py:32-36,46-48).  One workgroup per face.
-__global__ __launch_bounds__(256) void stn_fc_kernel(const float* __restrict__ xs, int fc, const float* __restrict__ w1,
+static __global__ __launch_bounds__(256) void stn_fc_kernel(const float* __restrict__ xs, int fc, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, int n1, const float* __restrict__ w2,
                                                       const float* __restrict__ b2, float* __restrict__ theta) {
     __shared__ float h[128];                                      // n1 = floor(sqrt(fc)) <= 85
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void stn_fc_kernel(const float* __restrict__ x
 // F.affine_grid(theta, size, align_corners=False) + F.grid_sample(bilinear, zeros, align_corners=False) on a
 // channels-last map (stn.py:50-51): base grid x_j = (2j + 1)/W - 1; source ix = ((gx + 1) W - 1) / 2.
 // Writes fp32 and the bf16 copy the following down/up GEMM loads.  One thread per (pixel, 4 channels).
-__global__ __launch_bounds__(256) void stn_grid_sample_kernel(const float* __restrict__ X, const float* __restrict__ theta,
+static __global__ __launch_bounds__(256) void stn_grid_sample_kernel(const float* __restrict__ X, const float* __restrict__ theta,
                                                                float* __restrict__ Y, unsigned short* __restrict__ Y16,
                                                                int B, int H, int C) {
     const int c4n = C >> 2;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void stn_grid_sample_kernel(const float* __res
 
 // x = a + b (decoder input = previous stage + encoder skip, model.py:82-83): fp32, bf16 copy and the LayerNorm
 // partial (one per row) of the sum.  One wave per row.
-__global__ __launch_bounds__(256) void add_rows_stats_kernel(const float* __restrict__ A, const float* __restrict__ Bv, float* __restrict__ X,
+static __global__ __launch_bounds__(256) void add_rows_stats_kernel(const float* __restrict__ A, const float* __restrict__ Bv, float* __restrict__ X,
                                                               unsigned short* __restrict__ X16, float2* __restrict__ stats, int M, int C) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;

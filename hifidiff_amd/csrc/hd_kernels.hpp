@@ -26,7 +26,7 @@ struct PackP {
     int N, Cin, Cin_pad, KH, KW, ntaps, centre_only, S2, Kp, nt_total;
     const float* nscale;
 };
-__global__ void pack_weight_kernel(const PackP p) {
+static __global__ void pack_weight_kernel(const PackP p) {
     const int ksteps = p.Kp >> 4;
     const size_t total = (size_t)p.nt_total * ksteps * 64;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -57,7 +57,7 @@ __global__ void pack_weight_kernel(const PackP p) {
 
 // 1x1 conv weight [N][K] fp32 -> bf16 in the A-operand order of v_mfma_f32_16x16x32_bf16 (hd_xcd2.hpp: the WEIGHTS are the A operand,
 // 16 output channels x 32 k per fragment): dst[(mb * K/32 + ks) * 64 + lane] = W[mb*16 + (lane & 15)][ks*32 + 8*(lane >> 4) .. + 7]
-__global__ void pack_weight16_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int N, int K) {
+static __global__ void pack_weight16_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int N, int K) {
     const int ksteps = K >> 5;
     const size_t total = (size_t)(N >> 4) * ksteps * 64;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -73,7 +73,7 @@ __global__ void pack_weight16_kernel(const float* __restrict__ src, uint4* __res
 }
 
 // depthwise weights [2C][9] -> tap-major [9][2C]: the fused conv1 epilogue reads them with one coalesced load per tap
-__global__ void dw_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT, int n2c) {
+static __global__ void dw_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT, int n2c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n2c * 9) return;
     const int ch = i / 9, t = i - ch * 9;
@@ -86,7 +86,7 @@ __global__ void dw_weight_layout_kernel(const float* __restrict__ w, float* __re
 // pixels of an image row, lanes over output channels (co = lane, lane + 64): the lane's 72 weights stay in
 // registers (wT is the weight re-laid as [ci*9 + tap][co]: coalesced loads), the 3 x 18 x 4 latent patch of
 // the run sits in LDS and is read as broadcasts.  The first thread also advances the loop's step counter.
-__global__ void intro_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT) {    // w[co][36] -> wT[36][co]
+static __global__ void intro_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT) {    // w[co][36] -> wT[36][co]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 128 * 36) return;
     const int co = i / 36;
@@ -171,7 +171,7 @@ __device__ __forceinline__ float sched_update(float xv, float e, const float* c,
     }
     return r;
 }
-__global__ void ending_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT) {   // w[co][ci][tap] -> wT[tap][co][ci]
+static __global__ void ending_weight_layout_kernel(const float* __restrict__ w, float* __restrict__ wT) {   // w[co][ci][tap] -> wT[tap][co][ci]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4 * 128 * 9) return;
     const int co = i / (128 * 9), r = i - co * 128 * 9, ci = r / 9, tap = r - ci * 9;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void ending_conv_kernel(const float* __restric
 // owns 32 gate channels x a band of 8 image rows of one face; each of its 8 row workers slides a 3x3 window along
 // its row (6 new values per pixel per gate half instead of 18).  Band sums go to pool_part[face][band][C]; the
 // mean over the face is finished by dwconv_pool_finish_kernel in band order (no atomics: reproducible).
-__global__ __launch_bounds__(256) void dwconv_gate_pool_kernel(const float* __restrict__ T1, const float* __restrict__ w2,
+static __global__ __launch_bounds__(256) void dwconv_gate_pool_kernel(const float* __restrict__ T1, const float* __restrict__ w2,
                                                                 const float* __restrict__ b2,
                                                                 unsigned short* __restrict__ G, float* __restrict__ pool_part,
                                                                 int H, int W, int C) {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_pool_kernel(const float* __re
         pool_part[((size_t)face * nbands + band) * C + j] = s;
     }
 }
-__global__ void dwconv_pool_finish_kernel(const float* __restrict__ pool_part, float* __restrict__ pooled, int faces, int nbands, int C, float inv_hw) {
+static __global__ void dwconv_pool_finish_kernel(const float* __restrict__ pool_part, float* __restrict__ pooled, int faces, int nbands, int C, float inv_hw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= faces * C) return;
     const int face = i / C, j = i - face * C;
@@ -335,7 +335,7 @@ __global__ void dwconv_pool_finish_kernel(const float* __restrict__ pool_part, f
 // -------------------------------------------------------------------------------------- FiLM path
 // sinusoidal embedding: [sin(t f_k), cos(t f_k)], k < 64 (models/denoiser/model.py:22-29).
 // f_k comes from the host (expf in fp32, like torch.exp on a float32 tensor).
-__global__ void time_embed_kernel(const float* __restrict__ t, const float* __restrict__ freq, float* __restrict__ out, int n) {
+static __global__ void time_embed_kernel(const float* __restrict__ t, const float* __restrict__ freq, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * 64) return;
     const int r = i >> 6, k = i & 63;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 //   out  = [b1*(1+scale_att)+shift_att, w1*(1+scale_att), b2*(1+scale_ffn)+shift_ffn, w2*(1+scale_ffn)]
 // ln holds [b1, w1, b2, w2] at the same offsets.  grid (ceil(C/256), n_blocks, rows).
 struct FilmBlock { int off, C; };
-__global__ void film_fold_kernel(float* __restrict__ film, const float* __restrict__ ln, const FilmBlock* __restrict__ blocks,
+static __global__ void film_fold_kernel(float* __restrict__ film, const float* __restrict__ ln, const FilmBlock* __restrict__ blocks,
                                  int film_total) {
     const FilmBlock fb = blocks[blockIdx.y];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -436,7 +436,7 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 // The sampling loop applies the scheduler update inside ending_conv_kernel (sched_update); this kernel serves
 // hd_scheduler_step.
 struct Coef7 { float c[7]; };
-__global__ void sched_step_direct_kernel(float* __restrict__ x, const float* __restrict__ eps, const Coef7 k,
+static __global__ void sched_step_direct_kernel(float* __restrict__ x, const float* __restrict__ eps, const Coef7 k,
                                          const float* __restrict__ noise, unsigned long long seed, int step, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -453,13 +453,13 @@ __global__ void sched_step_direct_kernel(float* __restrict__ x, const float* __r
 // A persistent stage of this call gave up a hand-off wait (abort word set): everything computed since is invalid, so the
 // call's result buffer is filled with NaN -- the caller sees the failure in the very tensors it gets back, whatever it does
 // with the return code (hd_check() reports it after a synchronisation).  One launch per hd_eps / hd_sample call.
-__global__ void poison_if_abort_kernel(const unsigned* __restrict__ abort_dev, float* __restrict__ out, size_t n) {
+static __global__ void poison_if_abort_kernel(const unsigned* __restrict__ abort_dev, float* __restrict__ out, size_t n) {
     if (*abort_dev == 0u) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = __builtin_nanf("");
 }
 
-__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, size_t total) {
+static __global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int p = (int)(i % HW);
@@ -470,7 +470,7 @@ __global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ in, float* __r
 }
 
 // avg + max pool over the face: HCA channel gate input (models/fpg/hca.py:34-36).  X fp32 [B][HW][C].
-__global__ void pool_avgmax_kernel(const float* __restrict__ X, float* __restrict__ out, int HW, int C) {
+static __global__ void pool_avgmax_kernel(const float* __restrict__ X, float* __restrict__ out, int HW, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float* p = X + (size_t)blockIdx.y * HW * C + c;
@@ -481,7 +481,7 @@ __global__ void pool_avgmax_kernel(const float* __restrict__ X, float* __restric
 
 // out[row] = sigmoid(dot(Hd[row], w) + bias): spatial gate's Conv2d(C/2,1,1)+BN (folded)+Sigmoid
 // (models/fpg/hca.py:16-18).  One wave per row, fp32.
-__global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(const float* __restrict__ Hd, const float* __restrict__ w, float bias,
+static __global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(const float* __restrict__ Hd, const float* __restrict__ w, float bias,
                                                               float* __restrict__ out, int M, int K) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(const float* __rest
 }
 
 // NCHW fp32 -> channels-last fp32 (priors handed in by hd_prepare_from_priors)
-__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, size_t total) {
+static __global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c = (int)(i % C);
@@ -503,7 +503,7 @@ __global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ in, float* __r
 }
 
 // cr_face NCHW fp32 [B,3,H,W] -> channels-last bf16 padded to 8 channels (ResNet conv1 input)
-__global__ void nchw3_to_nhwc8_bf16_kernel(const float* __restrict__ in, uint4* __restrict__ out, int HW, size_t npix) {
+static __global__ void nchw3_to_nhwc8_bf16_kernel(const float* __restrict__ in, uint4* __restrict__ out, int HW, size_t npix) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const size_t b = i / HW, p = i - b * HW;
@@ -512,7 +512,7 @@ __global__ void nchw3_to_nhwc8_bf16_kernel(const float* __restrict__ in, uint4* 
 }
 
 // MaxPool2d(3, stride 2, pad 1) on channels-last bf16 (models/idc/model.py:112,124)
-__global__ void maxpool3x3s2_bf16_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+static __global__ void maxpool3x3s2_bf16_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
                                          int B, int H, int W, int C) {
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)B * Ho * Wo * C;
@@ -534,7 +534,7 @@ __global__ void maxpool3x3s2_bf16_kernel(const unsigned short* __restrict__ in, 
 }
 
 // AdaptiveAvgPool2d(1) on channels-last bf16 -> fp32 [B][C] (models/idc/model.py:131)
-__global__ void avgpool_bf16_kernel(const unsigned short* __restrict__ in, float* __restrict__ out, int HW, int C) {
+static __global__ void avgpool_bf16_kernel(const unsigned short* __restrict__ in, float* __restrict__ out, int HW, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const unsigned short* p = in + (size_t)blockIdx.y * HW * C + c;

@@ -22,7 +22,7 @@ __device__ __forceinline__ void cubic_coeffs(float t, float* w) {
     w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
     w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
 }
-__global__ void bicubic_resize_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int Hin, int Win, int Hout, int Wout) {
+static __global__ void bicubic_resize_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int Hin, int Win, int Hout, int Wout) {
     const size_t total = (size_t)planes * Hout * Wout;
     const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -48,7 +48,7 @@ __global__ void bicubic_resize_kernel(const float* __restrict__ in, float* __res
 
 // NCHW fp32 (C <= 8 channels) -> channels-last bf16 with 8 channels per pixel (zero padded): the conv_in gather source
 // vae_range: first x.clamp(0, 1) * 2 - 1 (to_vae_range, train_refiner.py:60-65)
-__global__ void nchw_to_nhwc8_bf16_kernel(const float* __restrict__ in, uint4* __restrict__ out, int C, int HW, size_t npix, int vae_range) {
+static __global__ void nchw_to_nhwc8_bf16_kernel(const float* __restrict__ in, uint4* __restrict__ out, int C, int HW, size_t npix, int vae_range) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const size_t b = i / HW, px = i - b * HW;
@@ -63,7 +63,7 @@ __global__ void nchw_to_nhwc8_bf16_kernel(const float* __restrict__ in, uint4* _
 }
 
 // decoder entry: z / 0.18215 -> post_quant_conv (1x1, 4 -> 4) -> channels-last bf16 x 8
-__global__ void vae_decode_entry_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ b, uint4* __restrict__ out,
+static __global__ void vae_decode_entry_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ b, uint4* __restrict__ out,
                                         int HW, size_t npix, float inv_scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
@@ -79,7 +79,7 @@ __global__ void vae_decode_entry_kernel(const float* __restrict__ z, const float
 
 // encoder exit: moments [pixel][8] (conv_out) -> quant_conv (1x1, 8 -> 8) -> DiagonalGaussianDistribution.sample():
 // mean + exp(0.5 * clamp(logvar, -30, 20)) * noise, times the scaling factor; NCHW out.  noise: NCHW tensor or Philox.
-__global__ void vae_sample_kernel(const float* __restrict__ mom, const float* __restrict__ w, const float* __restrict__ b,
+static __global__ void vae_sample_kernel(const float* __restrict__ mom, const float* __restrict__ w, const float* __restrict__ b,
                                   const float* __restrict__ noise, unsigned long long seed, float* __restrict__ out, int HW, size_t npix,
                                   float scale, int ld) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,7 +106,7 @@ __global__ void vae_sample_kernel(const float* __restrict__ mom, const float* __
 
 // the posterior's parameters themselves: quant_conv(moments) as NCHW [B,8,L,L] (mean | logvar), what
 // AutoencoderKL.encode(x).latent_dist is built from
-__global__ void vae_moments_kernel(const float* __restrict__ mom, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+static __global__ void vae_moments_kernel(const float* __restrict__ mom, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
                                    int HW, size_t npix) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
@@ -124,7 +124,7 @@ __global__ void vae_moments_kernel(const float* __restrict__ mom, const float* _
 }
 
 // fp32 channels-last [pixel][ld] (first C columns) -> NCHW
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int ld, int HW, size_t npix) {
+static __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int ld, int HW, size_t npix) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix * C) return;
     const size_t px = i % HW, c = (i / HW) % C, f = i / ((size_t)HW * C);
@@ -132,7 +132,7 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restr
 }
 
 // nearest 2x upsampling of a channels-last fp32 map into bf16 (the gather source of Upsample2D's conv)
-__global__ void upsample2x_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int B, int H, int W, int C) {
+static __global__ void upsample2x_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int B, int H, int W, int C) {
     const size_t total = (size_t)B * 2 * H * 2 * W * (C / 8);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c8 = (int)(i % (C / 8));
@@ -150,7 +150,7 @@ __global__ void upsample2x_bf16_kernel(const float* __restrict__ in, unsigned sh
 // pass 1: per (face, chunk of pixels): sum and sum of squares of every group.  Coalesced float4 reads; thread t always
 // sees the same channel quad (t mod C/4), so its partial sums belong to one group.
 constexpr int GN_GROUPS = 32;
-__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int HW, int C, int chunk_px) {
+static __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int HW, int C, int chunk_px) {
     __shared__ double red[2][256];
     const int f = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     const int quads = C >> 2;                                     // float4 per pixel (C in {128, 256, 512})
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __r
     }
 }
 // pass 2: y = (x - mean_g) * rstd_g * gamma_c + beta_c [, SiLU] -> bf16
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, const double* __restrict__ part, int nchunks,
+static __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, const double* __restrict__ part, int nchunks,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               unsigned short* __restrict__ y, int HW, int C, int chunk_px, float eps, int silu) {
     __shared__ float mr[2][GN_GROUPS];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
 // q, k, v: fp32 [face][T][C] (C = 512).  One workgroup = 16 queries of one face; keys are visited in tiles of 64 with an
 // online softmax; K is staged in LDS in 128-channel slices, V is streamed.  out: bf16 [face][T][C] (to_out's operand).
 constexpr int AT_C = 512, AT_Q = 16, AT_K = 64;
-__global__ __launch_bounds__(256) void vae_attention_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+static __global__ __launch_bounds__(256) void vae_attention_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             unsigned short* __restrict__ out, int T, float scale) {
     extern __shared__ __attribute__((aligned(16))) float at_smem[];
     float* Qs = at_smem;                                          // [16][512]
