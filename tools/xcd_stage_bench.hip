@@ -35,7 +35,7 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale, float o
 template <class T> T* dmalloc(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); return p; }
 
 template <int C, int HW>
-void run(int nblocks, int B, int reps, int force_global, int no_a = 0, int no_w = 0) {
+void run(int nblocks, int B, int reps, int force_global, int no_a = 0, int no_w = 0, int alias_w = 0) {
     const int M = B * HW, NT = C / 32;
     std::vector<XBlockW> hb(nblocks);
     unsigned seed = 1;
@@ -48,6 +48,8 @@ void run(int nblocks, int B, int reps, int force_global, int no_a = 0, int no_w 
         b.beta = f(C, 0.2f, 0.f); b.gamma = f(C, 0.2f, 0.f); b.dw_w = f((size_t)9 * 2 * C, 0.3f, 0.f); b.dw_b = f(2 * C, 0.1f, 0.5f);
         b.film_off = (int)(&b - hb.data()) * 4 * C; b.pad_ = 0;
     }
+    if (alias_w)                       // what-if: every block and phase streams the SAME 2 C^2 weights (4 MB at C = 1024: about one XCD L2), values irrelevant
+        for (auto& b : hb) { b.w1 = hb[0].w1; b.w4 = hb[0].w1; b.wsca = hb[0].w1; b.w3 = hb[0].w1; b.w5 = hb[0].w1; }
     XStageP p{};
     p.B = B; p.nblocks = nblocks;
     XBlockW* db = dmalloc<XBlockW>(nblocks); CK(hipMemcpy(db, hb.data(), nblocks * sizeof(XBlockW), hipMemcpyHostToDevice)); p.blocks = db;
@@ -79,7 +81,7 @@ void run(int nblocks, int B, int reps, int force_global, int no_a = 0, int no_w 
     }
     std::vector<unsigned long long> h((size_t)P * 256 * 8);
     CK(hipMemcpy(h.data(), p.stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    if (no_a || no_w) printf("WHAT-IF%s%s (timing only): ", no_a ? " no activation loads" : "", no_w ? " no weight loads" : "");
+    if (no_a || no_w || alias_w) printf("WHAT-IF%s%s%s (timing only): ", no_a ? " no activation loads" : "", no_w ? " no weight loads" : "", alias_w ? " all phases read the same 2 C^2 weights (L2 / MALL resident)" : "");
     printf("C=%d HW=%d blocks=%d B=%d %s: kernel %.1f us = %.2f us per block, %.2f us per phase\n", C, HW, nblocks, B, force_global ? "global hand-off" : "local hand-off",
            best * 1e3, best * 1e3 / nblocks, best * 1e3 / P);
     auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
@@ -118,6 +120,7 @@ int main(int argc, char** argv) {
     }
 #endif
     run<1024, 4>(8, 64, reps, 0);
+    if (argc > 2 && atoi(argv[2]) == 9) { run<1024, 4>(8, 64, reps, 0, 0, 0, 1); run<1024, 4>(8, 64, reps, 0, 0, 1); return 0; }
     run<512, 16>(4, 64, reps, 0);
     run<1024, 4>(8, 64, reps, 1);
     run<1024, 4>(8, 64, reps, 0, 1, 0);
