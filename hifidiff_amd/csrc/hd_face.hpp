@@ -63,6 +63,9 @@ typedef __attribute__((address_space(1))) unsigned fs_gu32;
 // all B fragments of one column tile (K = C); the pointer comes from the LDS copy of the block table: say it is global
 template <int C>
 __device__ __forceinline__ void face_load_b(const uint4* W, int tile, int lane, uint4* b) {
+#ifdef HD_STAMPS
+    if (!W) return;                                                  // what-if build: FStageP::dbg_no_w hands in null weight pointers
+#endif
     const uint4* Wl = W + (size_t)tile * (C / 16) * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < C / 16; ++ks) b[ks] = xs_ldg_u4(Wl + ks * 64);
@@ -200,7 +203,7 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
         if constexpr (C == 128) face_load_b<C>(B.w1, tile + K::NT, lane, bw2);    // C = 256: one gate half at a time (registers)
         // per-channel constants of the depthwise stage: requested with the weights at C = 128; at C = 256 the two weight sets
         // already hold half the register file, so they (and the next GEMMs' weights) wait until conv1 has consumed them
-        constexpr bool kEarly = C == 128;
+        constexpr bool kEarly = C == 128;                            // (C = 256 with 16-row tiles and both halves up front: 107 spilled registers)
         float c_b1a = 0.f, c_b1b = 0.f, dwa[9], dwb[9], dba = 0.f, dbb = 0.f;
         auto load_dw_consts = [&]() __attribute__((always_inline)) {
             c_b1a = xs_ldg_f(B.b1 + col); c_b1b = xs_ldg_f(B.b1 + col + C);

@@ -54,6 +54,7 @@ struct FStageP {
     int block_limit;                       // introspection: stop after this many blocks (<= 0: all)
 #ifdef HD_STAMPS
     unsigned long long* stamps;            // [block][workgroup][8]
+    int dbg_no_w;                          // timing-only what-if (results are garbage): no weight loads
 #endif
 };
 struct X2StageP {

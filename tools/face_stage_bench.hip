@@ -27,9 +27,9 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale, float o
 }
 template <class T> T* dmalloc(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); return p; }
 
-template <int C>
-void run(int nblocks, int B, int reps) {
-    typedef FaceCfg<C> K;
+template <int C, int OWN>
+void run(int nblocks, int B, int reps, int no_w = 0) {
+    typedef FaceCfg<C, OWN> K;
     const int M = B * K::HW;
     std::vector<XBlockW> hb(nblocks);
     unsigned seed = 1;
@@ -38,6 +38,7 @@ void run(int nblocks, int B, int reps) {
         auto f = [&](size_t n, float sc, float off) { float* p = dmalloc<float>(n); fill_f32<<<64, 256>>>(p, n, seed++, sc, off); return (const float*)p; };
         const float ws = 1.0f / sqrtf((float)C);
         b.w1 = w((size_t)2 * C * C, ws); b.wsca = w((size_t)C * C, ws); b.w3 = w((size_t)C * C, ws); b.w4 = w((size_t)2 * C * C, ws); b.w5 = w((size_t)C * C, ws);
+        if (no_w) { b.w1 = nullptr; b.wsca = nullptr; b.w3 = nullptr; b.w4 = nullptr; b.w5 = nullptr; }     // face_load_b skips null pointers in the stamps build
         b.b1 = f(2 * C, 0.1f, 0.f); b.bsca = f(C, 0.1f, 1.f); b.b3 = f(C, 0.1f, 0.f); b.b4 = f(2 * C, 0.1f, 0.f); b.b5 = f(C, 0.1f, 0.f);
         b.beta = f(C, 0.2f, 0.f); b.gamma = f(C, 0.2f, 0.f); b.dw_w = f((size_t)9 * 2 * C, 0.3f, 0.f); b.dw_b = f(2 * C, 0.1f, 0.5f);
         b.film_off = (int)(&b - hb.data()) * 4 * C; b.pad_ = 0;
@@ -61,7 +62,7 @@ void run(int nblocks, int B, int reps) {
     float best = 1e9f;
     for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(e0, st));
-        CK((launch_face_stage<C>(p, st)));
+        CK((launch_face_stage<C, OWN>(p, st)));
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -69,10 +70,11 @@ void run(int nblocks, int B, int reps) {
         if (tmo_h[0]) { printf("TIMEOUT code 0x%x\n", tmo_h[0]); exit(2); }
     }
     int occ = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, naf_face_stage_kernel<C>, K::THREADS, K::SMEM));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, naf_face_stage_kernel<C, OWN>, K::THREADS, K::SMEM));
     std::vector<unsigned long long> h((size_t)nblocks * grid * 8);
     CK(hipMemcpy(h.data(), p.stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    printf("C=%d blocks=%d B=%d: %d workgroups of %d threads, %d B dynamic LDS, occupancy API says %d per CU; kernel %.1f us = %.2f us per block\n", C, nblocks, B, grid, K::THREADS,
+    if (no_w) printf("WHAT-IF no weight loads (timing only): ");
+    printf("C=%d rows/wg=%d blocks=%d B=%d: %d workgroups of %d threads, %d B dynamic LDS, occupancy API says %d per CU; kernel %.1f us = %.2f us per block\n", C, OWN, nblocks, B, grid, K::THREADS,
            K::SMEM, occ, best * 1e3, best * 1e3 / nblocks);
     auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     const char* nm[6] = {"wait+LN1", "conv1", "dw+gate", "pool xchg", "sca..conv5", "exit+publish"};
@@ -92,7 +94,8 @@ void run(int nblocks, int B, int reps) {
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
-    run<128>(2, 64, reps);
-    run<256>(2, 64, reps);
+    run<128, 32>(2, 64, reps); run<128, 32>(2, 64, reps, 1);
+    run<256, 16>(2, 64, reps); run<256, 16>(2, 64, reps, 1);
+    run<256, 32>(2, 64, reps);
     return 0;
 }
