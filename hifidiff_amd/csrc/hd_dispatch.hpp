@@ -43,6 +43,12 @@ hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
 // conv1 with the depthwise 3x3 + SimpleGate + pool fused: workgroup = whole faces (BM = max(32, hw) rows)
 template <class LN>
 hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
+    // many rows (latent 32: levels 2 / 3, M = 4096 / 1024): the 128-row deep-prefetch tile with the same epilogue -- every 128-row tile is whole faces
+    if constexpr (ld_is_deep<LN>::value) {
+        static const bool no_deep_dw = hd_env("HD_NO_DEEP_DW") != nullptr;
+        if (!no_deep_dw && deep_shape_ok<true>(p) && p.M % 128 == 0 && p.hw >= 4 && p.hw <= 128 && 128 % p.hw == 0 && p.side * p.side == p.hw)
+            return launch_gemm_deep<LN, EpDwGate, true>(p, s);
+    }
     // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle)
     if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LN, EpDwGate>(p, s);
     if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LN, EpDwGate>(p, s);

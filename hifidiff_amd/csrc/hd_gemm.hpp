@@ -1132,6 +1132,11 @@ __global__ __launch_bounds__(C::THREADS) void gemm_deep_kernel(const GemmP p) {
 // half's through LDS once, in the epilogue.  (With four waves a 128-row workgroup is one wave per SIMD and the chunk chain --
 // LDS reads, eight dependent MFMAs, transform, LDS writes, barrier -- has nothing to overlap with: 18.3 us against 17.6 us for
 // the skinny kernel at M = 1024.)
+template <int S>
+__device__ __forceinline__ float dw_gate_row(const float* t1a, const float* t1b, int p0, bool up, bool dn, const float* wa,
+                                             const float* wb, float ba, float bb, unsigned short* gout, int ldo, bool store_ok,
+                                             int rows_left);          // below (skinny kernel's tile epilogue)
+
 template <class LD, class EP, int NCH, int P>
 __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1187,6 +1192,15 @@ __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
     }
 #pragma unroll
     for (int d = 0; d < P; ++d) HD_DEEP_LOAD(d);
+    // fused depthwise epilogue (EpDwGate): its per-channel constants are requested now, not behind the K loop
+    float dw_w9[9], dw_bias = 0.f, dw_b1 = 0.f;
+    if constexpr (EP::kTile) {
+        const int ncols_e = p.N >> 1, ce = tile0 * 32 + (tid & 31) + ((tid >> 5) & 1) * ncols_e;      // odd half-waves: the second gate half's channel
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dw_w9[t] = p.dw_w[(size_t)t * p.N + ce];
+        dw_bias = p.dw_b[ce];
+        dw_b1 = p.bias[(half ? tile1 : tile0) * 32 + (lane & 31)];     // conv1 bias of THIS wave's accumulator columns
+    }
     LD::template block_init<BM, THREADS>(p, row0, smem + STATS_OFF, gb, tid);
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) LD::unit_stats(st[u], (tid >> 3) + u * (THREADS / 8), smem + STATS_OFF);
@@ -1213,6 +1227,73 @@ __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
     }
 #undef HD_DEEP_LOAD
 #undef HD_DEEP_WRITE
+    if constexpr (EP::kTile) {
+        // ====== conv1 bias -> depthwise 3x3 -> SimpleGate -> G, pooled on the 128-row tile (the tile epilogue of gemm_skinny_kernel;
+        // conditional_naf.py:116-119).  Both gate halves' T1 tiles go to LDS (the A buffers are dead: the loop ended with a barrier):
+        // t1[half][128 rows][32] fp32 = 32 KB, then one work item = (channel j, image row) as there.  With 32-row skinny tiles this
+        // GEMM put 1024 workgroups of 128 + 64 KB of operands on the chip (768 KB per CU: 21.8 - 23.6 us at latent 32, levels 3 / 2);
+        // on 128-row tiles it is the conv4 GEMM (16.4 - 16.8 us) plus this epilogue.
+        float* t1 = reinterpret_cast<float*>(smem);
+        float* rs = reinterpret_cast<float*>(smem + 2 * 128 * 32 * 4);     // [128 / S][32] row sums (<= 8 KB: behind the T1 tiles, over dead statistics / FiLM rows)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = w_m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            t1[(half * 128 + r) * 32 + (lane & 31)] = acc[i] + dw_b1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int C2 = p.N >> 1, ncols = C2;
+        const int j = tid & 31, col = tile0 * 32 + j;
+        const int S = p.side, ls = 31 - __builtin_clz(S), HW = p.hw;
+        // every thread holds the taps of ONE half (even half-waves: a, odd: b); the work item needs both: the partner's through LDS
+        float* wx = rs + (128 >> ls) * 32;                                  // [2][10][32] taps + bias of both halves
+        {
+            const int hb = (tid >> 5) & 1;
+            if ((tid >> 6) == 0) {                                           // wave 0: half-wave 0 holds half a, half-wave 1 half b
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wx[(hb * 10 + t) * 32 + j] = dw_w9[t];
+                wx[(hb * 10 + 9) * 32 + j] = dw_bias;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float wa[9], wb[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { wa[t] = wx[t * 32 + j]; wb[t] = wx[(10 + t) * 32 + j]; }
+        const float ba = wx[9 * 32 + j], bb = wx[19 * 32 + j];
+        const float* t1a = t1 + j;
+        const float* t1b = t1 + 128 * 32 + j;
+        const int nrows_img = 128 >> ls;
+        for (int rr = tid >> 5; rr < nrows_img; rr += THREADS / 32) {
+            const int p0 = rr << ls;
+            const int y = (p0 & (HW - 1)) >> ls;
+            const bool up = y > 0, dn = y < S - 1;
+            const int row = row0 + p0;
+            unsigned short* gout = reinterpret_cast<unsigned short*>(p.out) + (size_t)row * p.ldo + col;
+            const int left = p.M - row;
+            float rsum;
+            switch (S) {
+                case 16: rsum = dw_gate_row<16>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, true, left); break;
+                case 8: rsum = dw_gate_row<8>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, true, left); break;
+                case 4: rsum = dw_gate_row<4>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, true, left); break;
+                default: rsum = dw_gate_row<2>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, true, left); break;
+            }
+            rs[rr * 32 + j] = rsum;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int faces = 128 / HW;
+        for (int idx = tid; idx < faces * 32; idx += THREADS) {
+            const int f = idx >> 5;
+            float sacc = 0.f;
+            for (int r = 0; r < S; ++r) sacc += rs[(f * S + r) * 32 + j];
+            const int face = row0 / HW + f;
+            if (face * HW < p.M) {
+                const float pm = sacc / (float)HW;
+                p.pooled[(size_t)face * C2 + col] = pm;
+                if (p.pooled16) p.pooled16[(size_t)face * C2 + col] = f32_to_bf16_bits(pm);
+            }
+        }
+        (void)ncols;
+        return;
+    }
     // second gate half -> LDS (the A buffers are dead: the loop ended with a barrier), first half runs the pair epilogue
     float* xch = reinterpret_cast<float*>(smem);
     if (half) {
