@@ -49,8 +49,9 @@ hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
         if (!no_deep_dw && deep_shape_ok<true>(p) && p.M % 128 == 0 && p.hw >= 4 && p.hw <= 128 && 128 % p.hw == 0 && p.side * p.side == p.hw)
             return launch_gemm_deep<LN, EpDwGate, true>(p, s);
     }
-    // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle)
-    if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= 1024) return launch_skinny_auto<1, 2, true, LN, EpDwGate>(p, s);
+    // more than two 32-row workgroups per CU: 64-row tiles halve the weight re-reads (latent 32, levels 3 / middle).  At K = 2048
+    // (latent 32, middle level: 256 rows) already from two per CU on: 512 workgroups of 256 + 128 KB against 256 of 256 + 256 KB
+    if (p.hw <= 32 && 64 % p.hw == 0 && p.M % 64 == 0 && (p.M / 32) * (p.N / 64) >= (p.Kp >= 2048 ? 512 : 1024)) return launch_skinny_auto<1, 2, true, LN, EpDwGate>(p, s);
     if (p.hw <= 32) return launch_skinny_auto<1, 1, true, LN, EpDwGate>(p, s);
     static const bool big64 = hd_env("HD_NO_DW64_WM8") == nullptr;      // 256-row tiles (4 faces of 8x8) when 64-row tiles would put >= 4 workgroups on a CU
     if (p.hw == 64 && big64 && p.M % 256 == 0 && (p.M / 64) * (p.N / 64) >= 1024) return launch_skinny_auto<8, 1, true, LN, EpDwGate>(p, s);
