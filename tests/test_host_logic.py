@@ -200,3 +200,17 @@ def test_cr_manifest_and_synthetic_weights():
     sd = synth.cr_state_dict()
     b = sd["decoders.2.stn.fc_loc.2.bias"]
     assert abs(float(b[0]) - 1.0) < 0.1 and abs(float(b[4]) - 1.0) < 0.1 and float(b[[1, 2, 3, 5]].abs().max()) < 0.1
+
+
+def test_incremental_build_knows_what_each_unit_includes():
+    """_lib.build() recompiles a translation unit when a header it includes (directly or not) is newer than its object file: the stage
+    kernels live in hd_stages.hip (hd_face.hpp / hd_xcd.hpp / hd_xcd2.hpp), the host side in hd_lib.hip + hd_aux.hip over hd_internal.hpp,
+    and none of the GEMM launch tables depends on a stage kernel (an edit there must not rebuild them: 2 minutes each)."""
+    import os
+    deps = {os.path.basename(u): {os.path.basename(d) for d in _lib.unit_deps(u)} for u in _lib.UNITS}
+    assert {"hd_face.hpp", "hd_xcd.hpp", "hd_xcd2.hpp", "hd_stage_api.hpp", "hd_chain.hpp", "hd_gemm.hpp"} <= deps["hd_stages.hip"]
+    assert {"hd_internal.hpp", "hd_stage_api.hpp", "hd_gemm.hpp", "hifidiff_hip.h"} <= deps["hd_lib.hip"] and "hd_xcd2.hpp" not in deps["hd_lib.hip"]
+    assert "hd_internal.hpp" in deps["hd_aux.hip"]
+    for u in ("hd_dispatch_ln.hip", "hd_dispatch_lnface.hip", "hd_dispatch_bf16.hip", "hd_dispatch_misc.hip"):
+        assert deps[u] == {u, "hd_dispatch.hpp", "hd_gemm.hpp"}, deps[u]
+    assert set(os.path.basename(p) for p in _lib.SOURCES) >= set().union(*deps.values()) - {"hifidiff_hip.h"}
