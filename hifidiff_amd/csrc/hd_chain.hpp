@@ -19,6 +19,7 @@ struct ChainP {
     int M, hw, face0;                 // rows, rows per face, first face of this launch in the batch
     const unsigned short* G;          // [M][C] bf16 gate output of the fused conv1 kernel
     const float* pooled;              // [faces][C]
+    const float* pool_part; int pool_nparts; float pool_scale; float* pooled_out;   // or (pool_part != NULL): [faces][nparts][C] sums to add up, x scale; the mean is also stored
     const float* X;                   // [M][C] block input (residual)
     const uint4 *Wsca, *W3, *W4, *W5; // packed bf16 weights (K = C)
     const float *bsca, *b3, *b4, *b5, *beta, *gamma;
@@ -131,7 +132,20 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(c
         // lanes that hold row 0, under a branch, it was 16 load -> wait -> pack round trips in a row: most of this phase.
         float* pl = yt;
         const float* pv = p.pooled + (size_t)face * C;
-        for (int k = tid; k < C; k += K::THREADS) pl[k] = pv[k];
+        if (p.pool_part) {                                             // per-strip channel sums (hd_strip.hpp): fixed order, every workgroup of the face gets the same bits
+            const float* pp = p.pool_part + (size_t)face * p.pool_nparts * C;
+            for (int k = tid; k < C; k += K::THREADS) {
+                float v[8], s = 0.f;                                    // pool_nparts == 8 (host): eight loads in flight, then the sum in index order
+#pragma unroll
+                for (int b = 0; b < 8; ++b) v[b] = pp[b * C + k];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) s += v[b];
+                pl[k] = s * p.pool_scale;
+                if (row0 == face * p.hw) p.pooled_out[(size_t)face * C + k] = pl[k];      // introspection copy (the face's first workgroup)
+            }
+        } else {
+            for (int k = tid; k < C; k += K::THREADS) pl[k] = pv[k];
+        }
         __syncthreads();
         uint4 a[K::KS];
 #pragma unroll

@@ -645,7 +645,9 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         p.film_gain_off = bw.film_off + (2 * half + 1) * C;
         p.film_face_stride = 0; p.film_step_stride = 0; p.step_ptr = nullptr;
     };
-    static const bool no_fuse = hd_env("HD_NO_DWFUSE") != nullptr;
+    bool strip_pool = false;
+    static const bool no_fuse = hd_env("HD_NO_DWFUSE") != nullptr, no_chain = hd_env("HD_NO_CHAIN") != nullptr;
+    static const bool no_strip = hd_env("HD_NO_STRIP") != nullptr || no_fuse || no_chain;      // the chain kernel adds the strip sums up
     if (dwgate_ok(HW) && !no_fuse) {
         // LN1 + FiLM -> conv1 (+bias) -> depthwise 3x3 -> SimpleGate -> G, pooled mean: one launch
         GemmP p = base_gemm(bw.conv1, M);
@@ -653,6 +655,24 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
         p.out = lv.G; p.ldo = C; p.dw_w = bw.dw_wT; p.dw_b = bw.dw_b; p.pooled = lv.pooled; p.pooled16 = lv.pooled16; p.side = lv.H;
         add_gemm(c, prog, bw.name + ".conv2_gate_pool", p, LK_LN, EK_DWGATE);
+    } else if (C == 128 && lv.H == 32 && (*x_np) * (*x_cnt) == C && *x_np <= 16 && !no_strip) {
+        // 32 x 32 faces (latent 32, level 0): the same fusion by strips of 4 image rows, depthwise conv out of the MFMA accumulators (hd_strip.hpp)
+        StripP q{};
+        q.faces = M / HW; q.side = lv.H; q.C = C;
+        q.Xb = lv.Xb; q.stats_in = lv.sx; q.stats_np = *x_np; q.stats_cnt = *x_cnt;
+        q.W1 = bw.conv1.w; q.b1 = bw.conv1.bias; q.dw_wT = bw.dw_wT; q.dw_b = bw.dw_b;
+        q.film = static_film; q.film_gain_off = bw.film_off + C; q.film_bias_off = bw.film_off; q.film_face_stride = 0; q.face0 = c->ch->face0; q.ln_eps = 1e-6f;
+        q.G = lv.G; q.pool_part = lv.T1;                          // T1 itself is never written on this path: its first faces x 8 x C floats hold the strip sums
+        Chain* chp = c->ch;
+        Op op;
+        op.name = bw.name + ".conv2_gate_pool"; op.out = lv.G; op.out_elems = (size_t)M * C; op.out_bf16 = 1;
+        op.run = [c, chp, q](hipStream_t s) mutable -> hipError_t {
+            StripP r = q;
+            if (r.film == nullptr) { r.film = c->film_from_cur ? chp->film_cur : c->film_table; r.film_face_stride = c->film_face_stride; }
+            return run_strip_dwgate(r, s);
+        };
+        prog.push_back(op);
+        strip_pool = true;                                        // the chain kernel below adds the strip sums up itself (no pool_finish launch)
     } else {
         {   // LN1 + FiLM -> conv1 (+bias) -> T1
             GemmP p = base_gemm(bw.conv1, M);
@@ -680,12 +700,12 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
             prog.back().out = pooled; prog.back().out_elems = (size_t)faces * C;
         }
     }
-    static const bool no_chain = hd_env("HD_NO_CHAIN") != nullptr;
     if ((C == 128 || C == 256) && HW % 32 == 0 && !no_fuse && !no_chain) {        // also behind the unfused depthwise path (latent 32, level 0)
         // levels 0/1: sca -> conv3 -> residual -> LN+FiLM -> conv4 -> gate -> conv5 -> residual in ONE launch (hd_chain.hpp)
         ChainP q{};
         q.M = M; q.hw = HW; q.face0 = c->ch->face0;
         q.G = lv.G; q.pooled = lv.pooled; q.X = lv.X;
+        if (strip_pool) { q.pool_part = lv.T1; q.pool_nparts = lv.H / 4 /* = 8: the kernel's unrolled sum */; q.pool_scale = 1.0f / (float)HW; q.pooled_out = lv.pooled; }
         q.Wsca = bw.sca.w; q.W3 = bw.conv3.w; q.W4 = bw.conv4.w; q.W5 = bw.conv5.w;
         q.bsca = bw.sca.bias; q.b3 = bw.conv3.bias; q.b4 = bw.conv4.bias; q.b5 = bw.conv5.bias; q.beta = bw.beta; q.gamma = bw.gamma;
         q.film = static_film; q.film_bias_off = bw.film_off + 2 * C; q.film_gain_off = bw.film_off + 3 * C; q.ln_eps = 1e-6f;

@@ -77,10 +77,23 @@ struct X2StageP {
 #endif
 };
 
+// LayerNorm -> conv1 -> depthwise 3x3 -> SimpleGate of 32 x 32 faces, C = 128, by strips of 4 image rows (hd_strip.hpp)
+struct StripP {
+    int faces, side, C;                    // faces in the batch; face side (32) and channels (128): what the kernel is written for
+    const unsigned short* Xb;              // [faces * side^2][C] bf16 copy of the block input
+    const float2* stats_in; int stats_np, stats_cnt;     // its LayerNorm partials [rows][np] (mean, M2) of cnt channels each
+    const uint4* W1; const float* b1;      // conv1: packed bf16 B fragments (N = 2C), bias [2C]
+    const float *dw_wT, *dw_b;             // depthwise 3x3 weights tap-major [9][2C], bias [2C]
+    const float* film; int film_gain_off, film_bias_off, film_face_stride, face0; float ln_eps;
+    unsigned short* G;                     // [rows][C] bf16 gate
+    float* pool_part;                      // [faces][side / 4][C] channel sums of the gate per strip
+};
+
 // host entry points (hd_stages.hip).  C selects the instantiation: XCD-local stages 1024 (level 3, 2 x 2 faces) / 512 (level 2,
 // 4 x 4 faces); face-cluster stages 128 (level 0, 16 x 16 faces) / 256 (level 1, 8 x 8 faces: 16 rows per workgroup put it on all 256 CUs).  hipErrorInvalidValue otherwise.
 hipError_t run_xcd_stage(int C, const XStageP& p, hipStream_t s);
 hipError_t run_xcd2_stage(int C, const X2StageP& p, hipStream_t s);
+hipError_t run_strip_dwgate(const StripP& p, hipStream_t s);                        // hipErrorInvalidValue unless side = 32, C = 128
 hipError_t run_face_stage(int C, int own_rows, const FStageP& p, hipStream_t s);   // own_rows: pixel rows per workgroup, 32 (C = 128, 256) or 16 (C = 256)
 
 }  // namespace hd

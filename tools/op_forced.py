@@ -113,7 +113,7 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
                 # next launch's G is checked against the oracle's conv1 -> depthwise -> gate of the same input
                 report.append(f"{i:3d} {name:42s} (checked through the next launch's G)")
             elif kind == "conv2_gate_pool":
-                unfused = names[i - 1].endswith(".conv1")
+                unfused = names[i - 1].endswith(".conv1") or (H == 32 and C == 128)   # or by strips (hd_strip.hpp): the next launch adds the strip sums up
                 g = gate_of_x()
                 run_to(i + 1)
                 check(i, name, "G", _read(L, ctx, "G" + sl)[:M * C], _rows(PR.q(g)), True)
@@ -148,12 +148,20 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
             elif kind == "conv5":
                 fused = names[i - 1].endswith((".conv2_gate_pool", ".pool_finish"))      # levels 0/1: sca .. conv5 in one launch (hd_chain.hpp)
                 g = _nchw(_read(L, ctx, "G" + sl), B, C, H)
+                by_strips = fused and H == 32 and C == 128          # hd_strip.hpp left per-strip sums: this launch adds them up and stores the mean
                 if fused:
                     inp = _nchw(_read(L, ctx, "X" + sl), B, C, H)
-                    pooled = _read(L, ctx, "pooled" + sl)[:B * C].reshape(B, C, 1, 1)
+                    if by_strips:
+                        want_pool = gate_of_x().mean(dim=(2, 3)).reshape(-1)
+                    else:
+                        pooled = _read(L, ctx, "pooled" + sl)[:B * C].reshape(B, C, 1, 1)
                 else:
                     y = _nchw(_read(L, ctx, "Y" + sl), B, C, H)
                 run_to(i + 1)
+                if by_strips:
+                    pooled = _read(L, ctx, "pooled" + sl)[:B * C]
+                    check(i, name, "pooled", pooled, want_pool, False)
+                    pooled = pooled.reshape(B, C, 1, 1)
                 if fused:
                     sv = O._gemm_conv(pooled, P[p + ".sca.1.weight"], P[p + ".sca.1.bias"], PR)
                     y = inp + O._gemm_conv(PR.q(g * sv), P[p + ".conv3.weight"], P[p + ".conv3.bias"], PR) * P[p + ".beta"]
