@@ -86,8 +86,13 @@ __device__ __forceinline__ void chain_mma(const char* sA, const uint4* b, int la
                                                               __builtin_bit_cast(bf16x8_t, b[ks]), acc[mt], 0, 0, 0);
 }
 
+// C = 128, 32-row tiles: asked for three waves per SIMD the compiler needs 155 registers and no scratch (left alone it takes
+// 208 and two workgroups per CU); the kernel is a chain of dependent round trips, a third workgroup per CU fills them
+#ifndef HD_CHAIN_OCC
+#define HD_CHAIN_OCC 3
+#endif
 template <int C, int MT>
-__global__ __launch_bounds__((ChainCfg<C, MT>::THREADS)) void naf_chain_kernel(const ChainP p) {
+__global__ __launch_bounds__((ChainCfg<C, MT>::THREADS), (C == 128 && MT == 1 ? HD_CHAIN_OCC : 1)) void naf_chain_kernel(const ChainP p) {
     typedef ChainCfg<C, MT> K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -592,13 +592,24 @@ GemmP base_gemm(const PackedW& w, int M) {
     return p;
 }
 
-void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p, LdKind lk, EpKind ek) {
+// mode_hint: the caller's measured choice for its own shapes (the transitions below), unless HD_GEMM_MODE forces one
+void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p, LdKind lk, EpKind ek, int mode_hint = -1) {
     int t128 = choose_mode(p, ek == EK_GATE || ek == EK_DWGATE);   // (kernel mode; name kept for the capture list)
+    if (mode_hint >= 0 && hd_env("HD_GEMM_MODE") == nullptr) t128 = mode_hint;
     {   // many rows, long K, LayerNorm -> gate or bf16 -> residual (latent 32, levels 2 / 3): the deep-prefetch tall kernel; the
         // launch falls back to the mode above when the run-time shape does not fit (per-face timesteps)
         static const bool no_deep = hd_env("HD_NO_DEEP") != nullptr;
         const bool kinds = (lk == LK_LN && ek == EK_GATE) || (lk == LK_BF16 && ek == EK_RESID);
-        if (kinds && !no_deep && (ek == EK_GATE ? deep_shape_ok<true>(p) : deep_shape_ok<false>(p))) t128 |= 16;
+        if (kinds && !no_deep && mode_hint < 0 && (ek == EK_GATE ? deep_shape_ok<true>(p) : deep_shape_ok<false>(p))) t128 |= 16;
+    }
+    {   // tuning aid: HD_OP_MODE="downs.0=5,ups=2" overrides the mode of every launch whose name contains the key (first match)
+        static const std::string over = hd_env("HD_OP_MODE") ? hd_env("HD_OP_MODE") : "";
+        for (size_t at = 0; at < over.size();) {
+            const size_t end = over.find(',', at) == std::string::npos ? over.size() : over.find(',', at);
+            const size_t eq = over.find('=', at);
+            if (eq != std::string::npos && eq < end && name.find(over.substr(at, eq - at)) != std::string::npos) { t128 = atoi(over.c_str() + eq + 1); break; }
+            at = end + 1;
+        }
     }
     {   // each XCD re-fetches what its workgroups read: share the bigger operand through the XCD's L2
         const size_t a_bytes = (size_t)p.M * p.Kp * ((lk == LK_BF16 || lk == LK_BF16S || lk == LK_CONV_BF16 || lk == LK_LN) ? 2 : 4);
@@ -731,6 +742,10 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         *x_np = C / 32; *x_cnt = 32;
         return;
     }
+    // per-shape choices measured at batch 64, latent 32 (profiles/r04_mode_sweep_L32_blocks.txt), where choose_mode's rules (tuned on latent 16) are off:
+    // level 3 (1024 rows, C = 1024) conv3 / conv5 on 32-row tiles (12.9 -> 12.1 us each); level 2 (4096 rows, C = 512) conv3 / conv4 on the
+    // 64-row tall tile (17.8 -> 16.5, 16.5 -> 15.6 us)
+    const int hint35 = (M == 1024 && C == 1024) ? 3 : -1, hint3 = (M == 4096 && C == 512) ? 1 : hint35, hint4 = (M == 4096 && C == 512) ? 1 : -1;
     const bool prescale = dwgate_ok(HW) && !no_fuse && HW <= 16;      // fused conv1 wrote pooled16; few pixels per face (more rows serialise the epilogue)
     if (prescale) {
         {   // SCA on the bf16 pooled vector; its epilogue also scales G in place: G <- bf16(G * s)
@@ -743,7 +758,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
             p.A = lv.G; p.lda = C;
             p.out = lv.Y; p.ldo = C; p.resid = lv.X; p.ldr = C; p.rscale = bw.beta;
             p.stats_out = lv.sy; p.out16 = lv.Yb;
-            add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16, EK_RESID);
+            add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16, EK_RESID, hint3);
         }
     } else {
         {   // SCA 1x1 conv on the pooled vector
@@ -762,7 +777,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
             p.A = lv.G; p.lda = C; p.hw = HW; p.rowscale = lv.S;
             p.out = lv.Y; p.ldo = C; p.resid = lv.X; p.ldr = C; p.rscale = bw.beta;
             p.stats_out = lv.sy; p.out16 = lv.Yb;
-            add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16S, EK_RESID);
+            add_gemm(c, prog, bw.name + ".conv3", p, LK_BF16S, EK_RESID, hint3);
         }
     }
     {   // LN2 + FiLM -> conv4 -> SimpleGate -> G2 (bf16, reuses G)
@@ -770,7 +785,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         p.A = lv.Yb; p.lda = C; film_fields(p, 1);
         p.stats_in = lv.sy; p.stats_np = C / 32; p.stats_cnt = 32;
         p.out = lv.G; p.ldo = C;
-        add_gemm(c, prog, bw.name + ".conv4", p, LK_LN, EK_GATE);
+        add_gemm(c, prog, bw.name + ".conv4", p, LK_LN, EK_GATE, hint4);
     }
     {   // conv5 -> x' = y + gamma * (.)
         GemmP p = base_gemm(bw.conv5, M);
@@ -781,7 +796,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
             p.outg16 = lv.Xg; p.gate_c = gate->gate_c; p.gate_s = gate->gate_s; p.add_src = gate->add; p.hw = HW;
             p.stats_out = nullptr; p.out16 = nullptr;       // nothing normalises this tensor next
         }
-        add_gemm(c, prog, bw.name + ".conv5", p, LK_BF16, EK_RESID);
+        add_gemm(c, prog, bw.name + ".conv5", p, LK_BF16, EK_RESID, hint35);
     }
     *x_np = C / 32; *x_cnt = 32;
 }
@@ -791,7 +806,9 @@ void add_down(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const P
     p.A = src.Xb; p.lda = src.C; p.Hin = src.H; p.Win = src.H; p.Cin = src.C; p.KH = 2; p.KW = 2; p.stride = 2; p.pad = 0;
     p.Hout = dst.H; p.Wout = dst.H; p.ntaps = 4;          // gathers the bf16 copy conv5 wrote (same rounding point as before)
     p.out = dst.X; p.ldo = dst.C; p.stats_out = dst.sx; p.out16 = dst.Xb;
-    add_gemm(c, prog, name, p, LK_CONV_BF16, EK_BIASF32);
+    // many output rows (latent 32, levels 0 / 1 at batch 64): choose_mode's M-split workgroups were tuned on the blocks' GEMMs; the patch gather
+    // is faster on 32-row tiles (profiles/r04_mode_sweep_L32.txt: 33.5 -> 24.3 and 25.1 -> 22.8 us)
+    add_gemm(c, prog, name, p, LK_CONV_BF16, EK_BIASF32, dst.M >= 4096 ? 3 : -1);
 }
 
 // 1x1 conv (no bias) + PixelShuffle(r) + skip add, written in place over the skip buffer
@@ -801,7 +818,10 @@ void add_up(hd_ctx* c, std::vector<Op>& prog, const std::string& name, const Pac
     p.A = in; p.lda = C_in; p.Hin = H_in; p.Win = H_in; p.shuffle_r = r;
     p.out = out; p.ldo = w.N / (r * r); p.resid = skip; p.bias = nullptr;
     p.out16 = out16; p.stats_out = stats;
-    add_gemm(c, prog, name, p, in_bf16 ? LK_BF16 : LK_F32, EK_PIXSHUF);
+    // latent 32 at batch 64 (profiles/r04_mode_sweep_L32.txt): 32-row tiles from 4096 input rows on (48.9 -> 37.2, 36.4 -> 26.5 us);
+    // 1024 rows x K >= 1024: the 64-row tall tile (30.0 -> 22.8 us)
+    const int hint = M_in >= 4096 ? 3 : (M_in >= 1024 && M_in < 2048 && w.Kp >= 1024) ? 1 : -1;
+    add_gemm(c, prog, name, p, in_bf16 ? LK_BF16 : LK_F32, EK_PIXSHUF, hint);
 }
 
 // HCA conv on the pre-gated bf16 tensor Xg that the preceding conv5 epilogue wrote (hca.py:28-29,21-23): a
