@@ -140,9 +140,9 @@ __global__ __launch_bounds__((ChainCfg<C, MT>::THREADS), (C == 128 && MT == 1 ? 
         if (p.pool_part) {                                             // per-strip channel sums (hd_strip.hpp): fixed order, every workgroup of the face gets the same bits
             const float* pp = p.pool_part + (size_t)face * p.pool_nparts * C;
             for (int k = tid; k < C; k += K::THREADS) {
-                float v[8], s = 0.f;                                    // pool_nparts == 8 (host): eight loads in flight, then the sum in index order
+                float v[8], s = 0.f;                                    // pool_nparts <= 8 (host): all loads in flight, then the sum in index order
 #pragma unroll
-                for (int b = 0; b < 8; ++b) v[b] = pp[b * C + k];
+                for (int b = 0; b < 8; ++b) v[b] = b < p.pool_nparts ? pp[b * C + k] : 0.f;
 #pragma unroll
                 for (int b = 0; b < 8; ++b) s += v[b];
                 pl[k] = s * p.pool_scale;

@@ -659,15 +659,17 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
     bool strip_pool = false;
     static const bool no_fuse = hd_env("HD_NO_DWFUSE") != nullptr, no_chain = hd_env("HD_NO_CHAIN") != nullptr;
     static const bool no_strip = hd_env("HD_NO_STRIP") != nullptr || no_fuse || no_chain;      // the chain kernel adds the strip sums up
-    if (dwgate_ok(HW) && !no_fuse) {
+    const bool by_strips = ((C == 128 && lv.H == 32) || (C == 256 && lv.H == 16)) && (*x_np) * (*x_cnt) == C && *x_np <= 16 && !no_strip;
+    if (dwgate_ok(HW) && !no_fuse && !by_strips) {
         // LN1 + FiLM -> conv1 (+bias) -> depthwise 3x3 -> SimpleGate -> G, pooled mean: one launch
         GemmP p = base_gemm(bw.conv1, M);
         p.A = lv.Xb; p.lda = C; film_fields(p, 0);
         p.stats_in = lv.sx; p.stats_np = *x_np; p.stats_cnt = *x_cnt;
         p.out = lv.G; p.ldo = C; p.dw_w = bw.dw_wT; p.dw_b = bw.dw_b; p.pooled = lv.pooled; p.pooled16 = lv.pooled16; p.side = lv.H;
         add_gemm(c, prog, bw.name + ".conv2_gate_pool", p, LK_LN, EK_DWGATE);
-    } else if (C == 128 && lv.H == 32 && (*x_np) * (*x_cnt) == C && *x_np <= 16 && !no_strip) {
-        // 32 x 32 faces (latent 32, level 0): the same fusion by strips of 4 image rows, depthwise conv out of the MFMA accumulators (hd_strip.hpp)
+    } else if (by_strips) {
+        // 32 x 32 faces at C = 128, 16 x 16 at C = 256 (latent 32, levels 0 / 1): the same fusion by strips of 4 image rows, depthwise conv out of
+        // the MFMA accumulators (hd_strip.hpp)
         StripP q{};
         q.faces = M / HW; q.side = lv.H; q.C = C;
         q.Xb = lv.Xb; q.stats_in = lv.sx; q.stats_np = *x_np; q.stats_cnt = *x_cnt;
@@ -716,7 +718,7 @@ void add_naf_block(hd_ctx* c, std::vector<Op>& prog, const BlockW& bw, const Lev
         ChainP q{};
         q.M = M; q.hw = HW; q.face0 = c->ch->face0;
         q.G = lv.G; q.pooled = lv.pooled; q.X = lv.X;
-        if (strip_pool) { q.pool_part = lv.T1; q.pool_nparts = lv.H / 4 /* = 8: the kernel's unrolled sum */; q.pool_scale = 1.0f / (float)HW; q.pooled_out = lv.pooled; }
+        if (strip_pool) { q.pool_part = lv.T1; q.pool_nparts = lv.H / 4 /* 8 or 4 strips per face */; q.pool_scale = 1.0f / (float)HW; q.pooled_out = lv.pooled; }
         q.Wsca = bw.sca.w; q.W3 = bw.conv3.w; q.W4 = bw.conv4.w; q.W5 = bw.conv5.w;
         q.bsca = bw.sca.bias; q.b3 = bw.conv3.bias; q.b4 = bw.conv4.bias; q.b5 = bw.conv5.bias; q.beta = bw.beta; q.gamma = bw.gamma;
         q.film = static_film; q.film_bias_off = bw.film_off + 2 * C; q.film_gain_off = bw.film_off + 3 * C; q.ln_eps = 1e-6f;

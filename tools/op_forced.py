@@ -113,7 +113,7 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
                 # next launch's G is checked against the oracle's conv1 -> depthwise -> gate of the same input
                 report.append(f"{i:3d} {name:42s} (checked through the next launch's G)")
             elif kind == "conv2_gate_pool":
-                unfused = names[i - 1].endswith(".conv1") or (H == 32 and C == 128)   # or by strips (hd_strip.hpp): the next launch adds the strip sums up
+                unfused = names[i - 1].endswith(".conv1") or (H, C) in ((32, 128), (16, 256))   # or by strips (hd_strip.hpp): the next launch adds the strip sums up
                 g = gate_of_x()
                 run_to(i + 1)
                 check(i, name, "G", _read(L, ctx, "G" + sl)[:M * C], _rows(PR.q(g)), True)
@@ -148,7 +148,7 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
             elif kind == "conv5":
                 fused = names[i - 1].endswith((".conv2_gate_pool", ".pool_finish"))      # levels 0/1: sca .. conv5 in one launch (hd_chain.hpp)
                 g = _nchw(_read(L, ctx, "G" + sl), B, C, H)
-                by_strips = fused and H == 32 and C == 128          # hd_strip.hpp left per-strip sums: this launch adds them up and stores the mean
+                by_strips = fused and (H, C) in ((32, 128), (16, 256))          # hd_strip.hpp left per-strip sums: this launch adds them up and stores the mean
                 if fused:
                     inp = _nchw(_read(L, ctx, "X" + sl), B, C, H)
                     if by_strips:
