@@ -1083,14 +1083,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_deep_kernel(const GemmP p) {
         *reinterpret_cast<dq_u32x4*>(sBw + ((chunk) & 1) * B_BUF) = braw0[(chunk) % P];                    \
         if (FPW == 2) *reinterpret_cast<dq_u32x4*>(sBw + ((chunk) & 1) * B_BUF + 1024) = braw1[(chunk) % P]; \
     }
+    HD_STAMP(0);
 #pragma unroll
     for (int d = 0; d < P; ++d) HD_DEEP_LOAD(d);
+    HD_STAMP(1);
     // LayerNorm statistics / FiLM row: do not depend on the loads above (its workgroup barrier drains them once)
     LD::template block_init<C::BM, C::THREADS>(p, row0, smem + C::STATS_OFF, gb, tid);
 #pragma unroll
     for (int u = 0; u < C::UNITS; ++u) LD::unit_stats(st[u], (tid >> 3) + u * (C::THREADS / 8), smem + C::STATS_OFF);
     HD_DEEP_WRITE(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    HD_STAMP(2);
 
     const int a_lane_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
 #pragma unroll
@@ -1117,6 +1120,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_deep_kernel(const GemmP p) {
     }
 #undef HD_DEEP_LOAD
 #undef HD_DEEP_WRITE
+    HD_STAMP(3); HD_STAMP(4);
 
     const int ncols = C::PAIR ? (p.N >> 1) : p.N;
     const int rtile = row0 + w_m * 32;
@@ -1124,6 +1128,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_deep_kernel(const GemmP p) {
     const int col = tile0 * 32 + (lane & 31);
     if (rtile + 32 <= p.M) tile_epilogue_mfma<true, C::PAIR, EP>(p, acc[0], acc[C::PAIR ? 1 : 0], rbase, col, ncols, tile0, lane);
     else tile_epilogue_mfma<false, C::PAIR, EP>(p, acc[0], acc[C::PAIR ? 1 : 0], rbase, col, ncols, tile0, lane);
+    HD_STAMP(5);
 }
 
 // The same for a PAIR GEMM (LayerNorm -> conv4 -> SimpleGate) with EIGHT waves: four row tiles x the two gate halves.  A wave
@@ -1137,6 +1142,10 @@ __device__ __forceinline__ float dw_gate_row(const float* t1a, const float* t1b,
                                              const float* wb, float ba, float bb, unsigned short* gout, int ldo, bool store_ok,
                                              int rows_left);          // below (skinny kernel's tile epilogue)
 
+// (r04, tools/deep_bench.hip: at M = 1024, K = 1024 the K loop takes 10.3 of the launch's 17 us = 0.63 us per 64-deep chunk, and neither the
+// prefetch depth (P = 4 / 6 / 7: 10.3 / 10.1 / 9.8) nor requesting the fragments ahead of the next chunk's transform (10.3) nor two workgroups
+// per CU for the depthwise epilogue (128 registers, 4 spilled: 19.1 -> 20.9 us) moves it: per chunk ~120 KB cross the CU's LDS -- fragments read
+// by two (A) and four (B) waves each, FiLM gain / bias by every thread -- for 32 MFMAs)
 template <class LD, class EP, int NCH, int P>
 __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1190,8 +1199,10 @@ __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
                                        LD::finish_nc(p, st[u], (chunk) * BK, kq, raw[(chunk) % P][u], cc)); \
         *reinterpret_cast<dq_u32x4*>(sBw + ((chunk) & 1) * B_BUF) = braw[(chunk) % P];                     \
     }
+    HD_STAMP(0);
 #pragma unroll
     for (int d = 0; d < P; ++d) HD_DEEP_LOAD(d);
+    HD_STAMP(1);
     // fused depthwise epilogue (EpDwGate): its per-channel constants are requested now, not behind the K loop
     float dw_w9[9], dw_bias = 0.f, dw_b1 = 0.f;
     if constexpr (EP::kTile) {
@@ -1206,6 +1217,7 @@ __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
     for (int u = 0; u < UNITS; ++u) LD::unit_stats(st[u], (tid >> 3) + u * (THREADS / 8), smem + STATS_OFF);
     HD_DEEP_WRITE(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    HD_STAMP(2);
 
     const int a_lane_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
 #pragma unroll
@@ -1227,6 +1239,7 @@ __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
     }
 #undef HD_DEEP_LOAD
 #undef HD_DEEP_WRITE
+    HD_STAMP(3); HD_STAMP(4);
     if constexpr (EP::kTile) {
         // ====== conv1 bias -> depthwise 3x3 -> SimpleGate -> G, pooled on the 128-row tile (the tile epilogue of gemm_skinny_kernel;
         // conditional_naf.py:116-119).  Both gate halves' T1 tiles go to LDS (the A buffers are dead: the loop ended with a barrier):
@@ -1312,6 +1325,7 @@ __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
         if (rtile + 32 <= p.M) tile_epilogue_mfma<true, true, EP>(p, acc, acc2, rbase, col, ncols, tile0, lane);
         else tile_epilogue_mfma<false, true, EP>(p, acc, acc2, rbase, col, ncols, tile0, lane);
     }
+    HD_STAMP(5);
 }
 
 template <class EP, class = void> struct ep_is_sca_tile { static constexpr bool value = false; };
@@ -1815,10 +1829,13 @@ inline bool deep_shape_ok(const GemmP& p) {
     return p.K == p.Kp && (p.Kp == 512 || p.Kp == 1024) && p.M >= (PAIR ? 1024 : 2048) && ncols % 32 == 0 && p.film_face_stride == 0 &&
            ((p.M + 127) / 128) * (ncols / 32) >= 256;
 }
+#ifndef HD_DEEP_P
+#define HD_DEEP_P 4
+#endif
 template <class LD, class EP, bool PAIR>
 inline hipError_t launch_gemm_deep(const GemmP& p, hipStream_t s) {
     typedef Cfg<4, 1, 1, 1, PAIR> C;
-    constexpr int P = 4;                                  // chunks in flight per wave (A units + this wave's share of the B fragments)
+    constexpr int P = HD_DEEP_P;                          // chunks in flight per wave (A units + this wave's share of the B fragments)
     const int ncols = PAIR ? p.N / 2 : p.N;
     const int smem = C::SMEM + (LD::kGainBiasLds ? 2 * p.Kp * 4 : 0) + 2 * (PAIR ? 8 : 4) * 1024;     // + two B chunk buffers
     dim3 grid((p.M + C::BM - 1) / C::BM, ncols / 32, 1);
