@@ -34,9 +34,12 @@ struct ConvP {
 // STRIP: faces too large for LDS (32x32 pixels at level 0 of latent 32).  A workgroup's BM rows are whole image rows of one
 // face; it stages them plus the image row above and the one below (rows outside the face are never read: their taps
 // point at the zero row).
-template <int C_, int S_, int BM_, int MT_, int KS_, int DEPTH_ = 8, bool STRIP_ = false>
+// NT: 32-column output tiles per workgroup (each wave holds MT x NT accumulators and streams NT weight tiles).  One tile per workgroup
+// means C/32 workgroups stage the same faces; at latent 32 the staged faces fill most of the LDS (one workgroup per CU), so those
+// workgroups ran one after the other: 2-4 rounds of stage -> K loop -> epilogue.  NT = 2 / 4 makes every level one round there.
+template <int C_, int S_, int BM_, int MT_, int KS_, int DEPTH_ = 8, bool STRIP_ = false, int NT_ = 1>
 struct ConvCfg {
-    static constexpr int C = C_, S = S_, HW = S_ * S_, BM = BM_, MT = MT_, KS = KS_;
+    static constexpr int C = C_, S = S_, HW = S_ * S_, BM = BM_, MT = MT_, KS = KS_, NT = NT_;
     static constexpr bool STRIP = STRIP_;
     static constexpr int RG = BM / (32 * MT);                    // row groups
     static constexpr int WAVES = RG * KS, THREADS = 64 * WAVES;
@@ -48,7 +51,8 @@ struct ConvCfg {
     static constexpr int XIN = (NP + 1) * ROWB;                  // + one zero row for taps outside the face
     static constexpr int RED = KS > 1 ? KS * BM * 32 * 4 : 0;    // partial tiles (aliases the staging area)
     static constexpr int SMEM = XIN > RED ? XIN : RED;
-    static constexpr int DEPTH = DEPTH_;                         // weight fragments (1 KiB each) in flight per wave
+    static constexpr int DEPTH = DEPTH_;                         // weight fragments (1 KiB each) in flight per wave and column tile
+    static constexpr int OCC = (NT_ > 1 && C_ == 512) ? 4 : 1;   // waves per SIMD asked of the compiler: level 2 of latent 32 keeps two workgroups per CU (135 -> 128 registers)
     static_assert(WAVES == 8 || WAVES == 4, "4 or 8 waves");
     static_assert(NSTEP >= DEPTH, "prefetch ring longer than the loop");
     static_assert(SPT % KS == 0 && BM % (32 * MT) == 0, "shape");
@@ -57,7 +61,7 @@ struct ConvCfg {
 };
 
 template <class K>
-__global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
+__global__ __launch_bounds__((K::THREADS), (K::OCC)) void hca_conv_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int C = K::C, S = K::S, HW = K::HW, MT = K::MT, KS = K::KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,13 +77,15 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
     const int row0 = bx * K::BM;
     const int pix0 = K::STRIP ? row0 - S : (row0 / K::NP) * K::NP;   // first staged pixel (face aligned / one image row above the strip: may lie outside the face)
     // weights first: independent of everything else.  Step n = tap * CPW + j reads k-step tap * SPT + ksl * CPW + j.
-    uint4 bq[K::DEPTH];
-    const uint4* Wl = p.W + ((size_t)tile * K::KSTEPS + ksl * K::CPW) * 64 + lane;
+    uint4 bq[K::DEPTH][K::NT];
+    const uint4* Wl = p.W + ((size_t)tile * K::NT * K::KSTEPS + ksl * K::CPW) * 64 + lane;     // + t * KSTEPS * 64: column tile tile * NT + t
     // level 3 and deeper: 19+ MB of weights that only eight row groups share -> non-temporal stream (see gemm_skinny_kernel)
-#define HD_CONV_B(n) (K::C >= HD_CONV_NT_MINC ? nt_load_u4(&Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64]) \
-                                   : Wl[(size_t)(((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64])
+#define HD_CONV_B(n, t) (K::C >= HD_CONV_NT_MINC ? nt_load_u4(&Wl[(size_t)((t) * K::KSTEPS + ((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64]) \
+                                      : Wl[(size_t)((t) * K::KSTEPS + ((n) / K::CPW) * K::SPT + ((n) % K::CPW)) * 64])
 #pragma unroll
-    for (int d = 0; d < K::DEPTH; ++d) bq[d] = HD_CONV_B(d);
+    for (int d = 0; d < K::DEPTH; ++d)
+#pragma unroll
+        for (int t = 0; t < K::NT; ++t) bq[d][t] = HD_CONV_B(d, t);
 
     // ---- stage the faces (16-byte pieces, whole lines) and the zero row ----
     {
@@ -128,11 +134,13 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
             }
         }
     }
-    f32x16_t acc[MT];
+    f32x16_t acc[MT][K::NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        for (int t = 0; t < K::NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.f;
     __syncthreads();
 
     // ---- K loop, fully unrolled: 9 taps x CPW k-steps of this wave's channel slice ----
@@ -143,11 +151,15 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
         bf16x8_t a[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8_t*>(smem + src_off[mt][tap] + cbase + j * 32);
-        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, bq[n % K::DEPTH]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt], 0, 0, 0);
+        for (int t = 0; t < K::NT; ++t) {
+            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, bq[n % K::DEPTH][t]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b, acc[mt][t], 0, 0, 0);
+        }
         if (n + K::DEPTH < K::NSTEP) {
-            bq[n % K::DEPTH] = HD_CONV_B(n + K::DEPTH);
+#pragma unroll
+            for (int t = 0; t < K::NT; ++t) bq[n % K::DEPTH][t] = HD_CONV_B(n + K::DEPTH, t);
             // keep the refill HERE: left to itself the scheduler sinks it to just before its use DEPTH steps later (shorter
             // live range), i.e. issues it and waits for it at once -- a ring of depth 1-2 instead of DEPTH
             asm volatile("" ::: "memory");
@@ -155,43 +167,47 @@ __global__ __launch_bounds__((K::THREADS)) void hca_conv_kernel(const ConvP p) {
     }
 #undef HD_CONV_B
 
-    // ---- K-slice partials through LDS (slice order), then bias + ReLU + stores ----
-    const int col = tile * 32 + (lane & 31);
-    const float bias = p.bias[col];
-    if constexpr (KS > 1) {
-        __syncthreads();                                           // staged faces are dead
-        float* red = reinterpret_cast<float*>(smem);
+    // ---- K-slice partials through LDS (slice order), then bias + ReLU + stores; one column tile at a time ----
+    if constexpr (KS > 1) __syncthreads();                         // staged faces are dead
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int t = 0; t < K::NT; ++t) {
+        const int col = (tile * K::NT + t) * 32 + (lane & 31);
+        const float bias = p.bias[col];
+        if constexpr (KS > 1) {
+            float* red = reinterpret_cast<float*>(smem);
+            if (t > 0) __syncthreads();                            // the previous tile's partials have been read
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (rg * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                red[(ksl * K::BM + r) * 32 + (lane & 31)] = acc[mt][i];
-            }
-        __syncthreads();
-        for (int e = tid; e < K::BM * 32; e += K::THREADS) {
-            float v = bias;                                        // e & 31 == lane & 31 (THREADS % 32 == 0): same column
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) v += red[s * K::BM * 32 + e];
-            v = fmaxf(v, 0.f);
-            const int row = row0 + (e >> 5);
-            if (row < p.M) {
-                p.out[(size_t)row * C + col] = v;
-                if (p.out16) p.out16[(size_t)row * C + col] = f32_to_bf16_bits(v);
-            }
-        }
-    } else {
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (rg * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    red[(ksl * K::BM + r) * 32 + (lane & 31)] = acc[mt][t][i];
+                }
+            __syncthreads();
+            for (int e = tid; e < K::BM * 32; e += K::THREADS) {
+                float v = bias;                                    // e & 31 == lane & 31 (THREADS % 32 == 0): same column
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = row0 + (rg * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                const float v = fmaxf(acc[mt][i] + bias, 0.f);
+                for (int s = 0; s < KS; ++s) v += red[s * K::BM * 32 + e];
+                v = fmaxf(v, 0.f);
+                const int row = row0 + (e >> 5);
                 if (row < p.M) {
                     p.out[(size_t)row * C + col] = v;
                     if (p.out16) p.out16[(size_t)row * C + col] = f32_to_bf16_bits(v);
                 }
             }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = row0 + (rg * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    const float v = fmaxf(acc[mt][t][i] + bias, 0.f);
+                    if (row < p.M) {
+                        p.out[(size_t)row * C + col] = v;
+                        if (p.out16) p.out16[(size_t)row * C + col] = f32_to_bf16_bits(v);
+                    }
+                }
+        }
     }
 }
 
@@ -201,7 +217,7 @@ inline hipError_t launch_hca_conv(const ConvP& p, hipStream_t s) {
         static std::atomic<unsigned long long> granted{0};
         { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&hca_conv_kernel<K>), K::SMEM, granted); if (e != hipSuccess) return e; }
     }
-    hipLaunchKernelGGL((hca_conv_kernel<K>), dim3((p.M + K::BM - 1) / K::BM, K::C / 32), dim3(K::THREADS), K::SMEM, s, p);
+    hipLaunchKernelGGL((hca_conv_kernel<K>), dim3((p.M + K::BM - 1) / K::BM, K::C / (32 * K::NT)), dim3(K::THREADS), K::SMEM, s, p);
     return hipGetLastError();
 }
 
@@ -211,10 +227,15 @@ typedef ConvCfg<256, 8, 128, 2, 4, HD_CONV_DEPTH> ConvL1;     // two faces: 2 ro
 typedef ConvCfg<512, 4, 64, 2, 8, HD_CONV_DEPTH> ConvL2;      // four faces: 1 row group x 8 K-slices
 typedef ConvCfg<1024, 2, 32, 1, 8, 16> ConvL3; // eight faces; 590 KB of weights per workgroup: deeper ring
 // latent 32: faces of side 32 >> l; level 0's 32x32 faces do not fit LDS: strips of 8 image rows + halo (87 KB)
-typedef ConvCfg<128, 32, 256, 2, 2, HD_CONV_DEPTH, true> ConvL0x32;
-typedef ConvCfg<256, 16, 256, 2, 2> ConvL1x32;
-typedef ConvCfg<512, 8, 64, 2, 8> ConvL2x32;              // one face per workgroup, two per CU (two faces, one workgroup per CU: 28.9 against 26.6 us)
-typedef ConvCfg<1024, 4, 64, 2, 8, 16> ConvL3x32;         // four faces (134 KB): 16 row groups instead of 32 re-read every weight tile (42.9 -> 30.2 us)
-typedef ConvCfg<2048, 2, 32, 1, 8, 16> ConvL4x32;
+// (r04: one column tile per workgroup was 46.0 / 30.3 / 26.5 / 30.2 / 40.2 us for hcas.0 .. hcas.4 at batch 64; NT = 2 everywhere and 4 at
+// level 0: 43.8 / 26.4 / 29.4 / 27.3 / 29.1 -- level 2 loses its second workgroup per CU (167 registers; with half the ring and 128 registers asked of the compiler: 26.4, 5 spilled) and keeps NT = 1)
+#ifndef HD_CONV_L2X32_NT
+#define HD_CONV_L2X32_NT 1
+#endif
+typedef ConvCfg<128, 32, 256, 2, 2, 4, true, 4> ConvL0x32;
+typedef ConvCfg<256, 16, 256, 2, 2, 8, false, 2> ConvL1x32;
+typedef ConvCfg<512, 8, 64, 2, 8, (HD_CONV_L2X32_NT > 1 ? 4 : 8), false, HD_CONV_L2X32_NT> ConvL2x32;   // one face per workgroup, two per CU (two faces, one workgroup per CU: 28.9 against 26.6 us)
+typedef ConvCfg<1024, 4, 64, 2, 8, 8, false, 2> ConvL3x32;   // four faces (134 KB): 16 row groups instead of 32 re-read every weight tile (42.9 -> 30.2 us)
+typedef ConvCfg<2048, 2, 32, 1, 8, 8, false, 2> ConvL4x32;
 
 }  // namespace hd
