@@ -1,7 +1,9 @@
 // hd_dispatch.hpp -- the GEMM launch table, split by loader family so that the kernel instantiations compile in parallel
 // translation units (hd_dispatch_*.hip; one hipcc process each, linked into libhifidiff_hip.so).
 #pragma once
+#include <type_traits>
 #include "hd_gemm.hpp"
+#include "hd_wide.hpp"
 
 namespace hd {
 
@@ -11,8 +13,14 @@ enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE,
 // mode: 0 = tall T128, 1 = tall T64, 2 = skinny 64 rows, 3 = skinny 32 rows, 4 = tall T32W (32 rows x 256 cols),
 //       5 / 6 = skinny with 4 / 8 M-split waves (128 / 256 rows per workgroup; long-K gathers at large M)
 //       + 16: the deep-prefetch tall kernel where the loader / epilogue pair has it and the shape fits (latent 32: levels 2 / 3)
+//       + 32: the role-split wide kernel (hd_wide.hpp) for LayerNorm -> gate and bf16 -> residual at 1024 rows x K = 1024 (latent 32: level 3)
 template <class LD, class EP, bool PAIR>
 hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
+    constexpr bool kWideLN = std::is_same<LD, LdF32LN_T<false>>::value && std::is_same<EP, EpGateBF16>::value && PAIR;
+    constexpr bool kWidePlain = std::is_same<LD, LdBF16Plain>::value && std::is_same<EP, EpResidF32>::value && !PAIR;
+    if constexpr (kWideLN || kWidePlain) {
+        if ((mode & 32) && wide_shape_ok<PAIR>(p) && (!kWideLN || (p.stats_np <= 32 && p.stats_np * p.stats_cnt == p.K))) return launch_gemm_wide<kWideLN, EP, PAIR>(p, s);
+    }
     if constexpr (ld_is_deep<LD>::value && ep_is_deep<EP>::value) {
         if ((mode & 16) && deep_shape_ok<PAIR>(p)) return launch_gemm_deep<LD, EP, PAIR>(p, s);
     }

@@ -1146,6 +1146,9 @@ __device__ __forceinline__ float dw_gate_row(const float* t1a, const float* t1b,
 // prefetch depth (P = 4 / 6 / 7: 10.3 / 10.1 / 9.8) nor requesting the fragments ahead of the next chunk's transform (10.3) nor two workgroups
 // per CU for the depthwise epilogue (128 registers, 4 spilled: 19.1 -> 20.9 us) moves it: per chunk ~120 KB cross the CU's LDS -- fragments read
 // by two (A) and four (B) waves each, FiLM gain / bias by every thread -- for 32 MFMAs)
+#ifndef HD_DEEP_SKEW
+#define HD_DEEP_SKEW 0
+#endif
 template <class LD, class EP, int NCH, int P>
 __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1228,6 +1231,24 @@ __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
         }
         const char* sA = smem + (c & 1) * A_BUF + a_lane_off + (w_m * 32) * LDS_ROW;
         const char* sBc = sB + (c & 1) * B_BUF + (half * 4) * 1024 + lane * 16;
+#if HD_DEEP_SKEW
+        // the two waves of a SIMD (w and w + 4: the two gate halves) take the chunk's two jobs in opposite order -- one runs its four
+        // MFMAs while the other transforms and stores the next chunk -- instead of both queueing for the matrix pipe and then both for the VALU
+        dq_u32x4 fa[4], fb[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { fa[s4] = *reinterpret_cast<const dq_u32x4*>(sA + s4 * 32); fb[s4] = *reinterpret_cast<const dq_u32x4*>(sBc + s4 * 1024); }
+        if (half) {
+            if (c + 1 < NCH) HD_DEEP_WRITE(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[s4]), __builtin_bit_cast(bf16x8_t, fb[s4]), acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[s4]), __builtin_bit_cast(bf16x8_t, fb[s4]), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < NCH) HD_DEEP_WRITE(c + 1);
+        }
+#else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(sA + s4 * 32);
@@ -1235,6 +1256,7 @@ __global__ __launch_bounds__(512) void gemm_deep_pair8_kernel(const GemmP p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
         if (c + 1 < NCH) HD_DEEP_WRITE(c + 1);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #undef HD_DEEP_LOAD

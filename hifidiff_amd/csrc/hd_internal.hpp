@@ -602,6 +602,12 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
         const bool kinds = (lk == LK_LN && ek == EK_GATE) || (lk == LK_BF16 && ek == EK_RESID);
         if (kinds && !no_deep && mode_hint < 0 && (ek == EK_GATE ? deep_shape_ok<true>(p) : deep_shape_ok<false>(p))) t128 |= 16;
     }
+    {   // level 3 of latent 32 (1024 rows, K = 1024): the role-split wide kernel (hd_wide.hpp) for the LayerNorm -> gate and bf16 -> residual GEMMs;
+        // the launch falls back to the mode above when the run-time shape does not fit (per-face timesteps)
+        static const bool no_wide = hd_env("HD_NO_WIDE") != nullptr;
+        const bool pair = (lk == LK_LN && ek == EK_GATE), plain = (lk == LK_BF16 && ek == EK_RESID);
+        if (!no_wide && ((pair && wide_shape_ok<true>(p)) || (plain && wide_shape_ok<false>(p)))) t128 |= 32;
+    }
     {   // tuning aid: HD_OP_MODE="downs.0=5,ups=2" overrides the mode of every launch whose name contains the key (first match)
         static const std::string over = hd_env("HD_OP_MODE") ? hd_env("HD_OP_MODE") : "";
         for (size_t at = 0; at < over.size();) {

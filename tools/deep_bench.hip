@@ -7,8 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cmath>
+#include <cstring>
+#include <type_traits>
 #define HD_STAMPS 1
 #include "../hifidiff_amd/csrc/hd_gemm.hpp"
+#include "../hifidiff_amd/csrc/hd_wide.hpp"
 using namespace hd;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -42,7 +46,7 @@ static void report(unsigned long long* dev, int nwg, float us) {
     printf(" (median/max over %d workgroups)\n", nwg);
 }
 
-template <class LD, class EP, bool PAIR>
+template <class LD, class EP, bool PAIR, bool WIDE = false>
 void run(const char* name, int M, int K, int N, bool ln, int side = 0) {
     hipStream_t s; CK(hipStreamCreate(&s));
     const size_t wbytes = (size_t)N * K * 2;
@@ -73,24 +77,53 @@ void run(const char* name, int M, int K, int N, bool ln, int side = 0) {
         if (side) { p.side = side; p.hw = side * side; p.dw_w = dww; p.dw_b = bias; p.pooled = pooled; p.pooled16 = pooled16; }
         return p;
     };
+    auto launch = [&](const GemmP& q) -> hipError_t {
+        if constexpr (WIDE) return launch_gemm_wide<std::is_same<LD, LdF32LN_T<false>>::value, EP, PAIR>(q, s);
+        else return launch_gemm_deep<LD, EP, PAIR>(q, s);
+    };
+    if (WIDE ? !wide_shape_ok<PAIR>(base(0)) : !deep_shape_ok<PAIR>(base(0))) { printf("%s: shape not taken by this kernel\n", name); return; }
+    if constexpr (WIDE) {   // same inputs through the deep kernel first: the two outputs side by side
+        const size_t n = (size_t)M * ncols;
+        GemmP q = base(0);
+        CK((launch_gemm_deep<LD, EP, PAIR>(q, s))); CK(hipStreamSynchronize(s));
+        std::vector<unsigned short> h16(n); std::vector<float> h32(n);
+        CK(hipMemcpy(h16.data(), out16, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h32.data(), out, n * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(out16, 0, n * 2)); CK(hipMemset(out, 0, n * 4));
+        CK(launch(q)); CK(hipStreamSynchronize(s));
+        std::vector<unsigned short> g16(n); std::vector<float> g32(n);
+        CK(hipMemcpy(g16.data(), out16, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(g32.data(), out, n * 4, hipMemcpyDeviceToHost));
+        double num = 0, den = 0, mx = 0; size_t diff16 = 0;
+        auto b2f = [](unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; };
+        for (size_t i = 0; i < n; ++i) {
+            const double a = PAIR ? b2f(h16[i]) : h32[i], b = PAIR ? b2f(g16[i]) : g32[i];
+            num += (a - b) * (a - b); den += a * a; mx = std::max(mx, std::abs(a - b)); diff16 += h16[i] != g16[i];
+        }
+        printf("  wide vs deep kernel on the same inputs: rel-L2 %.3e, max abs %.3e, bf16 outputs that differ %zu of %zu (|ref| rms %.3e)\n", std::sqrt(num / (den + 1e-30)), mx, diff16, n, std::sqrt(den / n));
+    }
     (void)ln;
-    if (!deep_shape_ok<PAIR>(base(0))) { printf("%s: shape not taken by the deep kernel\n", name); return; }
-    for (int i = 0; i < 5; ++i) CK((launch_gemm_deep<LD, EP, PAIR>(base(i), s)));
+    for (int i = 0; i < 5; ++i) CK(launch(base(i)));
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 100;
     CK(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) CK((launch_gemm_deep<LD, EP, PAIR>(base(i), s)));
+    for (int i = 0; i < iters; ++i) CK(launch(base(i)));
     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     GemmP p = base(3); p.stamps = stamps;
-    CK((launch_gemm_deep<LD, EP, PAIR>(p, s))); CK(hipStreamSynchronize(s));
+    CK(launch(p)); CK(hipStreamSynchronize(s));
     printf("%s M=%d K=%d N=%d:\n", name, M, K, N);
     report(stamps, ((M + 127) / 128) * (ncols / 32), ms * 1000.f / iters);
     for (auto w : W) CK(hipFree(w));
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {     // the wide form (hd_wide.hpp) of the level-3 shapes against the deep kernel
+        run<LdF32LN_T<false>, EpGateBF16, true>("LN -> conv4 -> gate (pair8)", 1024, 1024, 2048, true);
+        run<LdF32LN_T<false>, EpGateBF16, true, true>("LN -> conv4 -> gate (WIDE)", 1024, 1024, 2048, true);
+        run<LdBF16Plain, EpResidF32, false, true>("bf16 -> conv5 -> residual (WIDE)", 1024, 1024, 1024, false);
+        run<LdBF16Plain, EpGateBF16, true, true>("WHAT-IF bf16 -> conv4 -> gate (WIDE, no LayerNorm)", 1024, 1024, 2048, false);
+        return 0;
+    }
     run<LdF32LN_T<false>, EpGateBF16, true>("LN -> conv4 -> gate (pair8)", 1024, 1024, 2048, true);
     run<LdF32LN_T<false>, EpGateBF16, true>("LN -> conv4 -> gate (pair8)", 4096, 512, 1024, true);
     run<LdBF16Plain, EpResidF32, false>("bf16 -> conv5 -> residual (deep)", 4096, 512, 512, false);
