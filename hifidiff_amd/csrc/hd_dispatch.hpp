@@ -52,6 +52,11 @@ hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
 template <class LN>
 hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
     // many rows (latent 32: levels 2 / 3, M = 4096 / 1024): the 128-row deep-prefetch tile with the same epilogue -- every 128-row tile is whole faces
+    if constexpr (std::is_same<LN, LdF32LN_T<false>>::value) {      // level 3 of latent 32: the role-split wide kernel with the same tile epilogue (hd_wide.hpp)
+        static const bool no_wide = hd_env("HD_NO_WIDE") != nullptr;
+        if (!no_wide && wide_shape_ok<true>(p) && p.stats_np <= 32 && p.stats_np * p.stats_cnt == p.K && p.hw >= 4 && p.hw <= 128 && 128 % p.hw == 0 && p.side * p.side == p.hw)
+            return launch_gemm_wide<true, EpDwGate, true>(p, s);
+    }
     if constexpr (ld_is_deep<LN>::value) {
         static const bool no_deep_dw = hd_env("HD_NO_DEEP_DW") != nullptr;
         if (!no_deep_dw && deep_shape_ok<true>(p) && p.M % 128 == 0 && p.hw >= 4 && p.hw <= 128 && 128 % p.hw == 0 && p.side * p.side == p.hw)

@@ -179,9 +179,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_barrier" ::: "memory");                         // the MFMA waves' exchange
-        return;
+        if constexpr (!EP::kTile) return;                               // (the depthwise epilogue below is work for all 512 threads)
     }
 #undef HD_WIDE_LOAD
+    f32x16_t mine[C::TNT];
+    if (!producer) {
     // the MFMA waves take their weight fragments straight from global memory (packed in fragment order: one coalesced 1 KiB load per
     // fragment): through LDS they were a third of the stage's LDS traffic (16 KB stored, 32 KB read per 128 k), and the LDS is what a
     // stage costs once the roles are split.  The two row halves request the same fragments (the second request hits L1 / L2).
@@ -235,7 +237,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
 
     // ---- the two K halves meet: wave (rh, kh) takes over row tile kh of its row half and gets the partner's partial of it ----
     float* xch = reinterpret_cast<float*>(smem);                       // [wave][TNT][16][64]: the staging buffers are dead (the loop ended with a barrier)
-    f32x16_t mine[C::TNT];
 #pragma unroll
     for (int t = 0; t < C::TNT; ++t) {
 #pragma unroll
@@ -253,12 +254,76 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
             const float o = xch[((partner * C::TNT + t) * 16 + i) * 64 + lane];
             mine[t][i] = kh ? o + mine[t][i] : mine[t][i] + o;         // K half 0 + K half 1, whoever adds
         }
-    const int ncols = PAIR ? (p.N >> 1) : p.N;
-    const int rtile = row0 + rh * 64 + kh * 32;
-    const int rbase = rtile + 4 * (lane >> 5);
-    const int col = tile0 * 32 + (lane & 31);
-    tile_epilogue_mfma<true, PAIR, EP>(p, mine[0], mine[PAIR ? 1 : 0], rbase, col, ncols, tile0, lane);
-    HD_STAMP(5);
+    }
+    if constexpr (EP::kTile) {
+        // ====== conv1 bias -> depthwise 3x3 -> SimpleGate -> G, pooled on the 128-row tile: gemm_deep_pair8_kernel's tile epilogue
+        // (conditional_naf.py:116-119), all 512 threads.  t1[half][128 rows][32] fp32 behind the exchange area.
+        float* t1 = reinterpret_cast<float*>(smem + 32768);
+        float* rs = reinterpret_cast<float*>(smem + 32768 + 2 * 128 * 32 * 4);     // [128 / S][32] row sums (over dead staging / statistics / FiLM rows)
+        const int S = p.side, ls = 31 - __builtin_clz(S), HW = p.hw;
+        float* wx = rs + (128 >> ls) * 32;                                  // [2][10][32] taps + bias of both halves
+        if (!producer) {
+#pragma unroll
+            for (int t = 0; t < C::TNT; ++t) {
+                const float b1 = p.bias[(t ? tile1 : tile0) * 32 + (lane & 31)];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = rh * 64 + kh * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    t1[(t * 128 + r) * 32 + (lane & 31)] = mine[t][i] + b1;
+                }
+            }
+        } else if (pw == 0) {                                               // one staging wave fetches the taps: half-wave 0 holds half a, half-wave 1 half b
+            const int hb = (tid >> 5) & 1, jj = tid & 31, ce = tile0 * 32 + jj + hb * (p.N >> 1);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wx[(hb * 10 + t) * 32 + jj] = p.dw_w[(size_t)t * p.N + ce];
+            wx[(hb * 10 + 9) * 32 + jj] = p.dw_b[ce];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int C2 = p.N >> 1;
+        const int j = tid & 31, col = tile0 * 32 + j;
+        float wa[9], wb[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { wa[t] = wx[t * 32 + j]; wb[t] = wx[(10 + t) * 32 + j]; }
+        const float ba = wx[9 * 32 + j], bb = wx[19 * 32 + j];
+        const float* t1a = t1 + j;
+        const float* t1b = t1 + 128 * 32 + j;
+        const int nrows_img = 128 >> ls;
+        for (int rr = tid >> 5; rr < nrows_img; rr += C::THREADS / 32) {
+            const int p0 = rr << ls;
+            const int y = (p0 & (HW - 1)) >> ls;
+            const bool up = y > 0, dn = y < S - 1;
+            const int row = row0 + p0;
+            unsigned short* gout = reinterpret_cast<unsigned short*>(p.out) + (size_t)row * p.ldo + col;
+            const int left = p.M - row;
+            float rsum;
+            switch (S) {
+                case 16: rsum = dw_gate_row<16>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, true, left); break;
+                case 8: rsum = dw_gate_row<8>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, true, left); break;
+                case 4: rsum = dw_gate_row<4>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, true, left); break;
+                default: rsum = dw_gate_row<2>(t1a, t1b, p0, up, dn, wa, wb, ba, bb, gout, p.ldo, true, left); break;
+            }
+            rs[rr * 32 + j] = rsum;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int faces = 128 / HW;
+        for (int idx = tid; idx < faces * 32; idx += C::THREADS) {
+            const int f = idx >> 5;
+            float sacc = 0.f;
+            for (int r = 0; r < S; ++r) sacc += rs[(f * S + r) * 32 + j];
+            const int face = row0 / HW + f;
+            const float pm = sacc / (float)HW;
+            p.pooled[(size_t)face * C2 + col] = pm;
+            if (p.pooled16) p.pooled16[(size_t)face * C2 + col] = f32_to_bf16_bits(pm);
+        }
+        HD_STAMP(5);
+    } else {
+        const int ncols = PAIR ? (p.N >> 1) : p.N;
+        const int rtile = row0 + rh * 64 + kh * 32;
+        const int rbase = rtile + 4 * (lane >> 5);
+        const int col = tile0 * 32 + (lane & 31);
+        tile_epilogue_mfma<true, PAIR, EP>(p, mine[0], mine[PAIR ? 1 : 0], rbase, col, ncols, tile0, lane);
+        HD_STAMP(5);
+    }
 }
 
 template <bool LN, class EP, bool PAIR>
