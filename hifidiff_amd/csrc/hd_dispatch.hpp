@@ -13,13 +13,14 @@ enum EpKind { EK_BIASF32, EK_RESID, EK_GATE, EK_PIXSHUF, EK_BIASBF16, EK_DWGATE,
 // mode: 0 = tall T128, 1 = tall T64, 2 = skinny 64 rows, 3 = skinny 32 rows, 4 = tall T32W (32 rows x 256 cols),
 //       5 / 6 = skinny with 4 / 8 M-split waves (128 / 256 rows per workgroup; long-K gathers at large M)
 //       + 16: the deep-prefetch tall kernel where the loader / epilogue pair has it and the shape fits (latent 32: levels 2 / 3)
-//       + 32: the role-split wide kernel (hd_wide.hpp) for LayerNorm -> gate and bf16 -> residual at 1024 rows x K = 1024 (latent 32: level 3)
+//       + 32: the role-split wide kernel (hd_wide.hpp) for LayerNorm -> gate and bf16 -> residual at 1024 rows x K = 1024 / 4096 rows x K = 512 (latent 32: levels 3 / 2)
 template <class LD, class EP, bool PAIR>
 hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
     constexpr bool kWideLN = std::is_same<LD, LdF32LN_T<false>>::value && std::is_same<EP, EpGateBF16>::value && PAIR;
     constexpr bool kWidePlain = std::is_same<LD, LdBF16Plain>::value && std::is_same<EP, EpResidF32>::value && !PAIR;
     if constexpr (kWideLN || kWidePlain) {
-        if ((mode & 32) && wide_shape_ok<PAIR>(p) && (!kWideLN || (p.stats_np <= 32 && p.stats_np * p.stats_cnt == p.K))) return launch_gemm_wide<kWideLN, EP, PAIR>(p, s);
+        // (the 256-row form measured no gain for these two: 15.9 against 15.8 us and 12.9 against 12.4 us at level 2; tools/deep_bench)
+        if ((mode & 32) && wide_shape_ok<PAIR>(p) == 1 && (!kWideLN || wide_stats_ok<PAIR>(p))) return launch_gemm_wide<kWideLN, EP, PAIR>(p, s);
     }
     if constexpr (ld_is_deep<LD>::value && ep_is_deep<EP>::value) {
         if ((mode & 16) && deep_shape_ok<PAIR>(p)) return launch_gemm_deep<LD, EP, PAIR>(p, s);
@@ -54,7 +55,7 @@ hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
     // many rows (latent 32: levels 2 / 3, M = 4096 / 1024): the 128-row deep-prefetch tile with the same epilogue -- every 128-row tile is whole faces
     if constexpr (std::is_same<LN, LdF32LN_T<false>>::value) {      // level 3 of latent 32: the role-split wide kernel with the same tile epilogue (hd_wide.hpp)
         static const bool no_wide = hd_env("HD_NO_WIDE") != nullptr;
-        if (!no_wide && wide_shape_ok<true>(p) && p.stats_np <= 32 && p.stats_np * p.stats_cnt == p.K && p.hw >= 4 && p.hw <= 128 && 128 % p.hw == 0 && p.side * p.side == p.hw)
+        if (!no_wide && wide_shape_ok<true>(p) && wide_stats_ok<true>(p) && p.hw >= 4 && p.hw <= 128 && 128 % p.hw == 0 && p.side * p.side == p.hw)
             return launch_gemm_wide<true, EpDwGate, true>(p, s);
     }
     if constexpr (ld_is_deep<LN>::value) {

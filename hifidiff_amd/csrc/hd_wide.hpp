@@ -45,25 +45,41 @@ typedef float f32x4_wi __attribute__((ext_vector_type(4)));
 #ifndef HD_WIDE_PB
 #define HD_WIDE_PB 2
 #endif
-template <bool PAIR>
+// TALL = false: 128 rows x 128 k per stage, the MFMA waves = 2 row halves x 2 K halves (level 3: 1024 rows, K = 1024);
+// TALL = true: 256 rows x 64 k per stage, the MFMA waves = 4 row quarters, no K split (level 2: 4096 rows, K = 512).  Both: 8 stages of 32 KB.
+template <bool PAIR, bool TALL>
 struct WideCfg {
-    static constexpr int BM = 128, BK = 128, THREADS = 512, TNT = PAIR ? 2 : 1, P = HD_WIDE_P;   // 4 MFMA waves + 4 staging waves; stages in flight
-    static constexpr int AROW = BK * 2 + 16;                     // bytes per staged row (256 B data + 16 B pad)
+    static constexpr int BM = TALL ? 256 : 128, BK = TALL ? 64 : 128, THREADS = 512, TNT = PAIR ? 2 : 1, P = HD_WIDE_P;   // 4 MFMA waves + 4 staging waves; stages in flight
+    static constexpr int UPR = BK / 8, RG = 256 / UPR;           // 16-byte units per staged row; rows covered by the 256 staging threads per pass (8 passes)
+    static constexpr int KSP = TALL ? 1 : 2, RW = 4 / KSP;       // K halves and row parts of the MFMA waves
+    static constexpr int TPRW = 256 / BM;                        // threads per row of the statistics merge
+    static constexpr int AROW = BK * 2 + 16;                     // bytes per staged row (+ 16 B pad)
     static constexpr int A_BUF = BM * AROW;
     static constexpr int A_OFF = 0, STATS_OFF = 2 * A_BUF, GB_OFF = STATS_OFF + BM * 8;   // + 2 K floats (LayerNorm form)
     static constexpr int PB = HD_WIDE_PB;                        // stages of weight fragments in flight per MFMA wave
 };
 
+// 0: not a shape of this kernel; 1: the 128-row form; 2: the 256-row form
 template <bool PAIR>
-inline bool wide_shape_ok(const GemmP& p) {
+inline int wide_shape_ok(const GemmP& p) {
     const int ncols = PAIR ? p.N / 2 : p.N;
-    return p.K == p.Kp && p.Kp == 1024 && p.M % 128 == 0 && p.M >= 1024 && p.M <= 2048 && ncols % 32 == 0 && p.film_face_stride == 0 && p.lda == p.K &&
-           (p.M / 128) * (ncols / 32) >= 256;
+    if (p.K != p.Kp || ncols % 32 != 0 || p.film_face_stride != 0 || p.lda != p.K) return 0;
+    if (p.Kp == 1024 && p.M % 128 == 0 && p.M >= 1024 && p.M <= 2048 && (p.M / 128) * (ncols / 32) >= 256) return 1;
+    static const bool no_tall = hd_env("HD_NO_WIDE_TALL") != nullptr;
+    if (!no_tall && p.Kp == 512 && p.M % 256 == 0 && p.M >= 4096 && (p.M / 256) * (ncols / 32) >= 256 && (p.M / 256) * (ncols / 32) <= 512) return 2;
+    return 0;
 }
 
-template <bool LN, class EP, bool PAIR, int NST>
+// the statistics merge takes up to 16 partials per thread: 32 per row in the 128-row form (two threads per row), 16 in the 256-row form
+template <bool PAIR>
+inline bool wide_stats_ok(const GemmP& p) {
+    const int form = wide_shape_ok<PAIR>(p);
+    return form != 0 && p.stats_np >= 1 && p.stats_np <= (form == 1 ? 32 : 16) && p.stats_np * p.stats_cnt == p.K;
+}
+
+template <bool LN, class EP, bool PAIR, bool TALL, int NST>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
-    typedef WideCfg<PAIR> C;
+    typedef WideCfg<PAIR, TALL> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,7 +87,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     // the matrix pipe and the VALU / LDS-store work of a stage run side by side instead of behind each other
     const bool producer = wave >= 4;
     const int pw = wave & 3, ptid = tid & 255;
-    const int rh = wave & 1, kh = (wave >> 1) & 1;
+    const int rh = pw % C::RW, kh = pw / C::RW;
     const int ksteps_total = p.Kp >> 4;
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.xcd_tile_affine && (gridDim.y & 7) == 0) {               // gemm_deep_kernel's block map: the row groups of a weight tile on one XCD
@@ -84,13 +100,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     HD_STAMP(0);
 
     // ---- staging roles: A unit (16 B) column q16 of rows r8 + 16 u; B fragments f = wave + 4 j -> (gate half f / 8, k-step f % 8) ----
-    const int q16 = ptid & 15, r8 = ptid >> 4;
+    const int q16 = ptid % C::UPR, r8 = ptid / C::UPR;
     const unsigned short* Ap = reinterpret_cast<const unsigned short*>(p.A) + (size_t)(row0 + r8) * p.lda + q16 * 8;
     u32x4 raw[C::P][8];
 #define HD_WIDE_LOAD(s)                                                                                            \
     {                                                                                                               \
         _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                               \
-            raw[(s) % C::P][u] = *reinterpret_cast<const u32x4*>(Ap + (size_t)(16 * u) * p.lda + (HD_WIDE_ASTAGE(s)) * C::BK);       \
+            raw[(s) % C::P][u] = *reinterpret_cast<const u32x4*>(Ap + (size_t)(C::RG * u) * p.lda + (HD_WIDE_ASTAGE(s)) * C::BK);    \
     }
     if (producer) {
 #pragma unroll
@@ -103,11 +119,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     float* gb = reinterpret_cast<float*>(smem + C::GB_OFF);
     if constexpr (LN) {
       if (!producer) {                                                 // the MFMA waves have nothing to do yet: they merge the statistics and stage the FiLM row
-        const int rl = tid >> 1, part = tid & 1, np = p.stats_np;
+        const int rl = tid / C::TPRW, part = tid % C::TPRW, np = p.stats_np;
         const float2* sp = p.stats_in + (size_t)(row0 + rl) * np;
         float2 s[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const int j = part + 2 * i; s[i] = j < np ? sp[j] : make_float2(0.f, -1.f); }      // M2 < 0 marks "no partial"
+        for (int i = 0; i < 16; ++i) { const int j = part + C::TPRW * i; s[i] = j < np ? sp[j] : make_float2(0.f, -1.f); }      // M2 < 0 marks "no partial"
         const float* f = LdF32LN_T<false>::film_row(p);
         for (int k = tid * 4; k < p.K; k += 256 * 4) {
             *reinterpret_cast<float4*>(gb + k) = *reinterpret_cast<const float4*>(f + p.film_gain_off + k);
@@ -117,13 +133,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
         float sm = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sm += s[i].y >= 0.f ? s[i].x : 0.f;
-        sm += dpp_mov<0xB1>(sm);                                    // lane ^ 1: the row's other thread
+        if (C::TPRW == 2) sm += dpp_mov<0xB1>(sm);                  // lane ^ 1: the row's other thread
         const float inv_np = 1.0f / (float)np, cnt = (float)p.stats_cnt;
         const float mean = sm * inv_np;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { const float d = s[i].x - mean; q += s[i].y >= 0.f ? fmaf(cnt * d, d, s[i].y) : 0.f; }
-        q += dpp_mov<0xB1>(q);
+        if (C::TPRW == 2) q += dpp_mov<0xB1>(q);
         const float var = q * (inv_np / cnt);
         if (part == 0) reinterpret_cast<float2*>(smem + C::STATS_OFF)[rl] = make_float2(mean, __frsqrt_rn(var + p.ln_eps));
       }
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
         if (producer)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            float2 st = reinterpret_cast<const float2*>(smem + C::STATS_OFF)[r8 + 16 * u];
+            float2 st = reinterpret_cast<const float2*>(smem + C::STATS_OFF)[r8 + C::RG * u];
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st.x), "+v"(st.y));      // two registers of their own (LdF32LN_T::unit_stats)
             mu[u] = -st.x * st.y; rs[u] = st.y;
         }
@@ -157,11 +173,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
                     const f32x2_t x = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
                     o[i] = pack2(__builtin_elementwise_fma(__builtin_elementwise_fma(x, r2, m2), g[i], b[i]));
                 }
-                *reinterpret_cast<u32x4*>(sA + 16 * u * C::AROW) = o;
+                *reinterpret_cast<u32x4*>(sA + C::RG * u * C::AROW) = o;
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<u32x4*>(sA + 16 * u * C::AROW) = raw[s % C::P][u];
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<u32x4*>(sA + C::RG * u * C::AROW) = raw[s % C::P][u];
         }
     };
     // two loops, one per role, with the same barriers: the staging waves' register rings and the MFMA waves' accumulators never
@@ -182,7 +198,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
         if constexpr (!EP::kTile) return;                               // (the depthwise epilogue below is work for all 512 threads)
     }
 #undef HD_WIDE_LOAD
-    f32x16_t mine[C::TNT];
+    constexpr int NM = C::KSP == 1 ? 2 : 1;                             // row tiles a MFMA wave finishes: both of its own (no K split) / one after the exchange
+    f32x16_t mine[NM][C::TNT];
     if (!producer) {
     // the MFMA waves take their weight fragments straight from global memory (packed in fragment order: one coalesced 1 KiB load per
     // fragment): through LDS they were a third of the stage's LDS traffic (16 KB stored, 32 KB read per 128 k), and the LDS is what a
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     {                                                                                                               \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
             _Pragma("unroll") for (int t = 0; t < C::TNT; ++t)                                                      \
-                breg[(s) % C::PB][j][t] = *reinterpret_cast<const u32x4*>(Wb[t] + (size_t)((HD_WIDE_BSTAGE(s)) * 8 + j) * 64); \
+                breg[(s) % C::PB][j][t] = *reinterpret_cast<const u32x4*>(Wb[t] + (size_t)((HD_WIDE_BSTAGE(s)) * (C::BK / 16) + j) * 64); \
     }
 #pragma unroll
     for (int d = 0; d < C::PB; ++d) HD_WIDE_BLOAD(d);
@@ -235,42 +252,53 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
 #undef HD_WIDE_BLOAD
     HD_STAMP(3); HD_STAMP(4);
 
-    // ---- the two K halves meet: wave (rh, kh) takes over row tile kh of its row half and gets the partner's partial of it ----
-    float* xch = reinterpret_cast<float*>(smem);                       // [wave][TNT][16][64]: the staging buffers are dead (the loop ended with a barrier)
+    if constexpr (C::KSP == 2) {
+        // ---- the two K halves meet: wave (rh, kh) takes over row tile kh of its row half and gets the partner's partial of it ----
+        float* xch = reinterpret_cast<float*>(smem);                   // [wave][TNT][16][64]: the staging buffers are dead (the loop ended with a barrier)
 #pragma unroll
-    for (int t = 0; t < C::TNT; ++t) {
+        for (int t = 0; t < C::TNT; ++t) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            xch[((wave * C::TNT + t) * 16 + i) * 64 + lane] = kh ? acc[0][t][i] : acc[1][t][i];      // the tile the partner keeps
-            mine[t][i] = kh ? acc[1][t][i] : acc[0][t][i];
+            for (int i = 0; i < 16; ++i) {
+                xch[((wave * C::TNT + t) * 16 + i) * 64 + lane] = kh ? acc[0][t][i] : acc[1][t][i];      // the tile the partner keeps
+                mine[0][t][i] = kh ? acc[1][t][i] : acc[0][t][i];
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int partner = rh + 2 * (1 - kh);
+#pragma unroll
+        for (int t = 0; t < C::TNT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float o = xch[((partner * C::TNT + t) * 16 + i) * 64 + lane];
+                mine[0][t][i] = kh ? o + mine[0][t][i] : mine[0][t][i] + o;         // K half 0 + K half 1, whoever adds
+            }
+    } else {
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int t = 0; t < C::TNT; ++t) mine[m][t] = acc[m][t];
+        asm volatile("s_barrier" ::: "memory");                         // (the staging waves' last barrier)
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const int partner = rh + 2 * (1 - kh);
-#pragma unroll
-    for (int t = 0; t < C::TNT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float o = xch[((partner * C::TNT + t) * 16 + i) * 64 + lane];
-            mine[t][i] = kh ? o + mine[t][i] : mine[t][i] + o;         // K half 0 + K half 1, whoever adds
-        }
     }
     if constexpr (EP::kTile) {
         // ====== conv1 bias -> depthwise 3x3 -> SimpleGate -> G, pooled on the 128-row tile: gemm_deep_pair8_kernel's tile epilogue
         // (conditional_naf.py:116-119), all 512 threads.  t1[half][128 rows][32] fp32 behind the exchange area.
-        float* t1 = reinterpret_cast<float*>(smem + 32768);
-        float* rs = reinterpret_cast<float*>(smem + 32768 + 2 * 128 * 32 * 4);     // [128 / S][32] row sums (over dead staging / statistics / FiLM rows)
+        constexpr int T1_OFF = C::KSP == 2 ? 32768 : 0;                     // behind the exchange area where there is one
+        float* t1 = reinterpret_cast<float*>(smem + T1_OFF);
+        float* rs = reinterpret_cast<float*>(smem + T1_OFF + 2 * C::BM * 32 * 4);  // [BM / S][32] row sums (over dead staging / statistics / FiLM rows)
         const int S = p.side, ls = 31 - __builtin_clz(S), HW = p.hw;
-        float* wx = rs + (128 >> ls) * 32;                                  // [2][10][32] taps + bias of both halves
+        float* wx = rs + (C::BM >> ls) * 32;                                // [2][10][32] taps + bias of both halves
         if (!producer) {
 #pragma unroll
             for (int t = 0; t < C::TNT; ++t) {
                 const float b1 = p.bias[(t ? tile1 : tile0) * 32 + (lane & 31)];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = rh * 64 + kh * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                    t1[(t * 128 + r) * 32 + (lane & 31)] = mine[t][i] + b1;
-                }
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = rh * 64 + (C::KSP == 2 ? kh : m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                        t1[(t * C::BM + r) * 32 + (lane & 31)] = mine[m][t][i] + b1;
+                    }
             }
         } else if (pw == 0) {                                               // one staging wave fetches the taps: half-wave 0 holds half a, half-wave 1 half b
             const int hb = (tid >> 5) & 1, jj = tid & 31, ce = tile0 * 32 + jj + hb * (p.N >> 1);
@@ -286,8 +314,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
         for (int t = 0; t < 9; ++t) { wa[t] = wx[t * 32 + j]; wb[t] = wx[(10 + t) * 32 + j]; }
         const float ba = wx[9 * 32 + j], bb = wx[19 * 32 + j];
         const float* t1a = t1 + j;
-        const float* t1b = t1 + 128 * 32 + j;
-        const int nrows_img = 128 >> ls;
+        const float* t1b = t1 + C::BM * 32 + j;
+        const int nrows_img = C::BM >> ls;
         for (int rr = tid >> 5; rr < nrows_img; rr += C::THREADS / 32) {
             const int p0 = rr << ls;
             const int y = (p0 & (HW - 1)) >> ls;
@@ -305,7 +333,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
             rs[rr * 32 + j] = rsum;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int faces = 128 / HW;
+        const int faces = C::BM / HW;
         for (int idx = tid; idx < faces * 32; idx += C::THREADS) {
             const int f = idx >> 5;
             float sacc = 0.f;
@@ -318,23 +346,32 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
         HD_STAMP(5);
     } else {
         const int ncols = PAIR ? (p.N >> 1) : p.N;
-        const int rtile = row0 + rh * 64 + kh * 32;
-        const int rbase = rtile + 4 * (lane >> 5);
         const int col = tile0 * 32 + (lane & 31);
-        tile_epilogue_mfma<true, PAIR, EP>(p, mine[0], mine[PAIR ? 1 : 0], rbase, col, ncols, tile0, lane);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int rtile = row0 + rh * 64 + (C::KSP == 2 ? kh : m) * 32;
+            tile_epilogue_mfma<true, PAIR, EP>(p, mine[m][0], mine[m][PAIR ? 1 : 0], rtile + 4 * (lane >> 5), col, ncols, tile0, lane);
+        }
         HD_STAMP(5);
     }
 }
 
-template <bool LN, class EP, bool PAIR>
-inline hipError_t launch_gemm_wide(const GemmP& p, hipStream_t s) {
-    typedef WideCfg<PAIR> C;
+template <bool LN, class EP, bool PAIR, bool TALL>
+inline hipError_t launch_gemm_wide_inst(const GemmP& p, hipStream_t s) {
+    typedef WideCfg<PAIR, TALL> C;
     const int ncols = PAIR ? p.N / 2 : p.N;
     const int smem = C::GB_OFF + (LN ? 2 * p.Kp * 4 : 0);
     static std::atomic<unsigned long long> granted{0};
-    { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&gemm_wide_kernel<LN, EP, PAIR, 8>), 160 * 1024, granted); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL((gemm_wide_kernel<LN, EP, PAIR, 8>), dim3(p.M / C::BM, ncols / 32, 1), dim3(C::THREADS), smem, s, p);
+    { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&gemm_wide_kernel<LN, EP, PAIR, TALL, 8>), 160 * 1024, granted); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL((gemm_wide_kernel<LN, EP, PAIR, TALL, 8>), dim3(p.M / C::BM, ncols / 32, 1), dim3(C::THREADS), smem, s, p);
     return hipGetLastError();
+}
+template <bool LN, class EP, bool PAIR>
+inline hipError_t launch_gemm_wide(const GemmP& p, hipStream_t s) {
+    const int form = wide_shape_ok<PAIR>(p);                            // both forms: K / BK = 8 stages
+    if (form == 1) return launch_gemm_wide_inst<LN, EP, PAIR, false>(p, s);
+    if (form == 2) return launch_gemm_wide_inst<LN, EP, PAIR, true>(p, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace hd

@@ -124,6 +124,12 @@ int main(int argc, char** argv) {
         run<LdBF16Plain, EpGateBF16, true, true>("WHAT-IF bf16 -> conv4 -> gate (WIDE, no LayerNorm)", 1024, 1024, 2048, false);
         run<LdF32LN_T<false>, EpDwGate, true>("LN -> conv1 -> depthwise -> gate (pair8)", 1024, 1024, 2048, true, 4);
         run<LdF32LN_T<false>, EpDwGate, true, true>("LN -> conv1 -> depthwise -> gate (WIDE)", 1024, 1024, 2048, true, 4);
+        run<LdF32LN_T<false>, EpGateBF16, true>("LN -> conv4 -> gate (pair8)", 4096, 512, 1024, true);
+        run<LdF32LN_T<false>, EpGateBF16, true, true>("LN -> conv4 -> gate (WIDE, 256 rows)", 4096, 512, 1024, true);
+        run<LdBF16Plain, EpResidF32, false>("bf16 -> conv5 -> residual (deep)", 4096, 512, 512, false);
+        run<LdBF16Plain, EpResidF32, false, true>("bf16 -> conv5 -> residual (WIDE, 256 rows)", 4096, 512, 512, false);
+        run<LdF32LN_T<false>, EpDwGate, true>("LN -> conv1 -> depthwise -> gate (pair8)", 4096, 512, 1024, true, 8);
+        run<LdF32LN_T<false>, EpDwGate, true, true>("LN -> conv1 -> depthwise -> gate (WIDE, 256 rows)", 4096, 512, 1024, true, 8);
         return 0;
     }
     run<LdF32LN_T<false>, EpGateBF16, true>("LN -> conv4 -> gate (pair8)", 1024, 1024, 2048, true);
