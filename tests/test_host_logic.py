@@ -212,5 +212,6 @@ def test_incremental_build_knows_what_each_unit_includes():
     assert {"hd_internal.hpp", "hd_stage_api.hpp", "hd_gemm.hpp", "hifidiff_hip.h"} <= deps["hd_lib.hip"] and "hd_xcd2.hpp" not in deps["hd_lib.hip"]
     assert "hd_internal.hpp" in deps["hd_aux.hip"]
     for u in ("hd_dispatch_ln.hip", "hd_dispatch_lnface.hip", "hd_dispatch_bf16.hip", "hd_dispatch_misc.hip"):
-        assert deps[u] == {u, "hd_dispatch.hpp", "hd_gemm.hpp"}, deps[u]
+        assert deps[u] == {u, "hd_dispatch.hpp", "hd_gemm.hpp", "hd_wide.hpp"}, deps[u]      # hd_wide.hpp: a GEMM kernel of the launch table, not a stage
+    assert {"hd_strip.hpp", "hd_chain.hpp", "hd_stage_api.hpp"} <= deps["hd_strip.hip"] and "hd_strip.hpp" not in deps["hd_lib.hip"]
     assert set(os.path.basename(p) for p in _lib.SOURCES) >= set().union(*deps.values()) - {"hifidiff_hip.h"}
