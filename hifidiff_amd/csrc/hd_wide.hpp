@@ -21,6 +21,7 @@
 //   * the statistics merge handles the K / 32 = 32 partials per row with two threads per row in the equal-count form (the
 //     loader's fast path stops at 16 partials per row and fell back to Chan's update with its divisions: most of the 3.3 us
 //     ahead of the first chunk).
+// (Requesting the residual epilogue's operands behind the last K stages moved nothing: 2.3 -> 2.1 us of epilogue, same launch time -- it is stores.)
 // Arithmetic and rounding points are the loaders' (LdF32LN_T<false>, LdBF16Plain) and the epilogues' own (tile_epilogue_mfma);
 // the accumulation order differs (two K halves), which the parity tests' tolerance covers like any other tile shape.
 #pragma once
@@ -77,6 +78,11 @@ inline bool wide_stats_ok(const GemmP& p) {
     return form != 0 && p.stats_np >= 1 && p.stats_np <= (form == 1 ? 32 : 16) && p.stats_np * p.stats_cnt == p.K;
 }
 
+#ifdef HD_STAMPS     // tools/deep_bench: per-stage stamps of workgroup 0's first staging wave (role 1) and first MFMA wave (role 0), slots 4096 + role * 64 + 4 stage + k
+#define HD_WSTAMP(role, s, k) do { if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && pw == 0) p.stamps[4096 + (role) * 64 + 4 * (s) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HD_WSTAMP(role, s, k) do { } while (0)
+#endif
 template <bool LN, class EP, bool PAIR, bool TALL, int NST>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     typedef WideCfg<PAIR, TALL> C;
@@ -153,7 +159,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
         }
     }
     // stage -> LDS: the LayerNorm transform (two fused multiply-adds per element, round to nearest even) on the way in
-    auto write_stage = [&](int s) __attribute__((always_inline)) {
+    // ls >= 0: the loads of stage ls are requested one unit at a time between the units' transforms: a wave that requests eight units in a row
+    // stands at the issue of its vector-memory instructions until the CU's load path has taken them (0.5-0.7 us per stage: this CU takes in
+    // 64 KB per stage), and only then starts on the transform (0.7 us)
+    auto write_stage = [&](int s, int ls) __attribute__((always_inline)) {
         char* sA = smem + C::A_OFF + (s & 1) * C::A_BUF + r8 * C::AROW + q16 * 16;
         if constexpr (LN) {
             typedef __attribute__((address_space(3))) const float lds_f1;
@@ -174,25 +183,39 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
                     o[i] = pack2(__builtin_elementwise_fma(__builtin_elementwise_fma(x, r2, m2), g[i], b[i]));
                 }
                 *reinterpret_cast<u32x4*>(sA + C::RG * u * C::AROW) = o;
+                if (ls >= 0) {
+                    raw[ls % C::P][u] = *reinterpret_cast<const u32x4*>(Ap + (size_t)(C::RG * u) * p.lda + (HD_WIDE_ASTAGE(ls)) * C::BK);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<u32x4*>(sA + C::RG * u * C::AROW) = raw[s % C::P][u];
+            for (int u = 0; u < 8; ++u) {
+                *reinterpret_cast<u32x4*>(sA + C::RG * u * C::AROW) = raw[s % C::P][u];
+                if (ls >= 0) {
+                    raw[ls % C::P][u] = *reinterpret_cast<const u32x4*>(Ap + (size_t)(C::RG * u) * p.lda + (HD_WIDE_ASTAGE(ls)) * C::BK);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     };
     // two loops, one per role, with the same barriers: the staging waves' register rings and the MFMA waves' accumulators never
     // live in the same code (in one loop with a branch per role the allocator kept both sets: 218 registers spilled)
     if (producer) {
-        write_stage(0);
+#ifdef HD_WIDE_PRIO
+        __builtin_amdgcn_s_setprio(HD_WIDE_PRIO);                      // the staging wave's instructions ahead of the MFMA wave's on the shared SIMD
+#endif
+        write_stage(0, -1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int s = 0; s < NST; ++s) {
-            if (s + C::P < NST) {
-                HD_WIDE_LOAD(s + C::P);
-                asm volatile("" ::: "memory");                          // keep the requests here (see gemm_deep_kernel)
-            }
-            if (s + 1 < NST) write_stage(s + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            HD_WSTAMP(1, s, 0);
+            HD_WSTAMP(1, s, 1);
+            if (s + 1 < NST) write_stage(s + 1, s + C::P < NST ? s + C::P : -1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            HD_WSTAMP(1, s, 2);
+            asm volatile("s_barrier" ::: "memory");
+            HD_WSTAMP(1, s, 3);
         }
         asm volatile("s_barrier" ::: "memory");                         // the MFMA waves' exchange
         if constexpr (!EP::kTile) return;                               // (the depthwise epilogue below is work for all 512 threads)
@@ -228,6 +251,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     const int a_lane_off = (rh * 64 + (lane & 31)) * C::AROW + (lane >> 5) * 16 + kh * 4 * 32;
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
+        HD_WSTAMP(0, s, 0);
         const char* sA = smem + C::A_OFF + (s & 1) * C::A_BUF + a_lane_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -247,7 +271,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
             HD_WIDE_BLOAD(s + C::PB);
             asm volatile("" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HD_WSTAMP(0, s, 2);
+        asm volatile("s_barrier" ::: "memory");
+        HD_WSTAMP(0, s, 3);
     }
 #undef HD_WIDE_BLOAD
     HD_STAMP(3); HD_STAMP(4);

@@ -45,6 +45,18 @@ static void report(unsigned long long* dev, int nwg, float us) {
     for (int i = 0; i < 5; ++i) { if (i == 3) continue; std::sort(d[i].begin(), d[i].end()); printf(" %s %.2f/%.2f", nm[i], d[i][d[i].size() / 2], d[i].back()); }
     printf(" (median/max over %d workgroups)\n", nwg);
 }
+// hd_wide.hpp: per-stage stamps of workgroup 0 (HD_WSTAMP)
+static void report_wide(unsigned long long* dev) {
+    std::vector<unsigned long long> h(128);
+    CK(hipMemcpy(h.data(), dev + 4096, 128 * 8, hipMemcpyDeviceToHost));
+    if (!h[64]) return;
+    const unsigned long long t0 = std::min(h[0], h[64]);
+    printf("  workgroup 0, per stage (us from the first stamp): staging wave [start, loads issued, stage s+1 stored, barrier passed] | MFMA wave [start, -, MFMAs + weight requests done, barrier passed]\n");
+    for (int s = 0; s < 8; ++s) {
+        printf("    stage %d: staging %.2f %.2f %.2f %.2f | MFMA %.2f %.2f %.2f\n", s, (h[64 + 4 * s] - t0) * 0.01, (h[64 + 4 * s + 1] - t0) * 0.01, (h[64 + 4 * s + 2] - t0) * 0.01,
+               (h[64 + 4 * s + 3] - t0) * 0.01, (h[4 * s] - t0) * 0.01, (h[4 * s + 2] - t0) * 0.01, (h[4 * s + 3] - t0) * 0.01);
+    }
+}
 
 template <class LD, class EP, bool PAIR, bool WIDE = false>
 void run(const char* name, int M, int K, int N, bool ln, int side = 0) {
@@ -109,10 +121,12 @@ void run(const char* name, int M, int K, int N, bool ln, int side = 0) {
     for (int i = 0; i < iters; ++i) CK(launch(base(i)));
     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemset(stamps, 0, 8192 * 8 * 8));
     GemmP p = base(3); p.stamps = stamps;
     CK(launch(p)); CK(hipStreamSynchronize(s));
     printf("%s M=%d K=%d N=%d:\n", name, M, K, N);
     report(stamps, ((M + 127) / 128) * (ncols / 32), ms * 1000.f / iters);
+    if constexpr (WIDE) report_wide(stamps);
     for (auto w : W) CK(hipFree(w));
 }
 
