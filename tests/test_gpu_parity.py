@@ -1065,3 +1065,36 @@ def test_multi_rank_code_path_at_one_rank_over_rccl(gpu):
     assert cfg["rccl_world_size"] == 1 and cfg["output_finite"] is True and res["n_gpus"] == 1
     assert cfg["faces_per_rank"] == [64] and cfg["diffusion_steps"] == 20
     assert "gather_faces: all_gather over nccl, world 1" in r.stderr, r.stderr[-2000:]
+
+
+_L32_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from hifidiff_amd import _lib, synth
+from hifidiff_amd.refiner import FacialRefiner
+torch.set_grad_enabled(False)
+m = FacialRefiner(32); m.load_state_dict(synth.refiner_state_dict(32)); m.to("cuda:0")
+x, crl, crf = synth.sample_inputs(64, 32)
+e = m(x.cuda(), 500, crf.cuda(), crl.cuda()).sample.cpu()
+torch.save({"eps": e, "launches": _lib.lib().hd_num_ops(m.engine.ctx, 0)}, sys.argv[2])
+"""
+
+
+def test_latent32_strip_and_wide_kernels_against_the_launch_forms_they_replace(gpu, tmp_path):
+    """hd_strip.hpp (levels 0 / 1) and hd_wide.hpp (levels 2 / 3) at batch 64, latent 32, against the forms they replace (unfused conv1 ->
+    depthwise -> pool finish, fused-epilogue GEMM on whole faces, deep-prefetch tall kernels), which a fresh child process selects with
+    HD_NO_STRIP / HD_NO_WIDE (read once per process): 151 against 159 launches, the same eps up to accumulation order and the bf16
+    rounding of values that differ by it.  Each form on its own is held against the oracle launch by launch in the test above."""
+    import subprocess
+    from hifidiff_amd import _lib, synth
+    out = str(tmp_path / "eps_old_forms.pt")
+    env = dict(os.environ, HD_EXPERIMENTS="1", HD_NO_STRIP="1", HD_NO_WIDE="1")
+    r = subprocess.run([sys.executable, "-c", _L32_CHILD, ROOT, out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    old = torch.load(out)
+    m = make_model(synth.refiner_state_dict(32), 32)
+    x, crl, crf = synth.sample_inputs(64, 32)
+    e = m(x.cuda(), 500, crf.cuda(), crl.cuda()).sample.cpu()
+    n = _lib.lib().hd_num_ops(m.engine.ctx, 0)
+    assert (n, old["launches"]) == (151, 159), (n, old["launches"])
+    assert bool(torch.isfinite(e).all()) and rel_l2(e, old["eps"]) <= 3e-3, rel_l2(e, old["eps"])
