@@ -1098,3 +1098,9 @@ def test_latent32_strip_and_wide_kernels_against_the_launch_forms_they_replace(g
     n = _lib.lib().hd_num_ops(m.engine.ctx, 0)
     assert (n, old["launches"]) == (151, 159), (n, old["launches"])
     assert bool(torch.isfinite(e).all()) and rel_l2(e, old["eps"]) <= 3e-3, rel_l2(e, old["eps"])
+    # the same faces twice in a batch of 128 (level 3: 2048 rows, still the wide kernel's 128-row form; level 2: 8192 rows, its 256-row form with
+    # 512 workgroups; levels 0 / 1: 1024 and 512 strips): both halves must reproduce the batch-64 result up to tile-rule differences
+    m2 = make_model(synth.refiner_state_dict(32), 32)
+    x2, crl2, crf2 = torch.cat([x, x]), torch.cat([crl, crl]), torch.cat([crf, crf])
+    e2 = m2(x2.cuda(), 500, crf2.cuda(), crl2.cuda()).sample.cpu()
+    assert rel_l2(e2[:64], e) <= 3e-3 and rel_l2(e2[64:], e) <= 3e-3, (rel_l2(e2[:64], e), rel_l2(e2[64:], e))
