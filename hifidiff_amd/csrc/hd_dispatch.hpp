@@ -20,7 +20,9 @@ hipError_t launch_tile(const GemmP& p, int mode, hipStream_t s) {
     constexpr bool kWidePlain = std::is_same<LD, LdBF16Plain>::value && std::is_same<EP, EpResidF32>::value && !PAIR;
     if constexpr (kWideLN || kWidePlain) {
         // (the 256-row form measured no gain for these two: 15.9 against 15.8 us and 12.9 against 12.4 us at level 2; tools/deep_bench)
-        if ((mode & 32) && wide_shape_ok<PAIR>(p) == 1 && (!kWideLN || wide_stats_ok<PAIR>(p))) return launch_gemm_wide<kWideLN, EP, PAIR>(p, s);
+        // (the 64-row form: the LayerNorm pair GEMM of the middle level only)
+        const int form = (mode & 32) ? wide_shape_ok<PAIR>(p) : 0;
+        if ((form == 1 || (form == 3 && kWideLN)) && (!kWideLN || wide_stats_ok<PAIR>(p))) return launch_gemm_wide<kWideLN, EP, PAIR>(p, s);
     }
     if constexpr (ld_is_deep<LD>::value && ep_is_deep<EP>::value) {
         if ((mode & 16) && deep_shape_ok<PAIR>(p)) return launch_gemm_deep<LD, EP, PAIR>(p, s);
@@ -55,7 +57,8 @@ hipError_t dispatch_dwgate(const GemmP& p, hipStream_t s) {
     // many rows (latent 32: levels 2 / 3, M = 4096 / 1024): the 128-row deep-prefetch tile with the same epilogue -- every 128-row tile is whole faces
     if constexpr (std::is_same<LN, LdF32LN_T<false>>::value) {      // level 3 of latent 32: the role-split wide kernel with the same tile epilogue (hd_wide.hpp)
         static const bool no_wide = hd_env("HD_NO_WIDE") != nullptr;
-        if (!no_wide && wide_shape_ok<true>(p) && wide_stats_ok<true>(p) && p.hw >= 4 && p.hw <= 128 && 128 % p.hw == 0 && p.side * p.side == p.hw)
+        const int form = wide_shape_ok<true>(p);
+        if (!no_wide && form && wide_stats_ok<true>(p) && p.hw >= 4 && wide_form_rows(form) % p.hw == 0 && p.side * p.side == p.hw)
             return launch_gemm_wide<true, EpDwGate, true>(p, s);
     }
     if constexpr (ld_is_deep<LN>::value) {

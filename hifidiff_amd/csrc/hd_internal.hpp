@@ -606,7 +606,7 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
         // the launch falls back to the mode above when the run-time shape does not fit (per-face timesteps)
         static const bool no_wide = hd_env("HD_NO_WIDE") != nullptr;
         const bool pair = (lk == LK_LN && ek == EK_GATE), plain = (lk == LK_BF16 && ek == EK_RESID);
-        if (!no_wide && ((pair && wide_shape_ok<true>(p) == 1) || (plain && wide_shape_ok<false>(p) == 1))) t128 |= 32;
+        if (!no_wide && ((pair && (wide_shape_ok<true>(p) == 1 || wide_shape_ok<true>(p) == 3)) || (plain && wide_shape_ok<false>(p) == 1))) t128 |= 32;
     }
     {   // tuning aid: HD_OP_MODE="downs.0=5,ups=2" overrides the mode of every launch whose name contains the key (first match)
         static const std::string over = hd_env("HD_OP_MODE") ? hd_env("HD_OP_MODE") : "";

@@ -46,36 +46,41 @@ typedef float f32x4_wi __attribute__((ext_vector_type(4)));
 #ifndef HD_WIDE_PB
 #define HD_WIDE_PB 2
 #endif
-// TALL = false: 128 rows x 128 k per stage, the MFMA waves = 2 row halves x 2 K halves (level 3: 1024 rows, K = 1024);
-// TALL = true: 256 rows x 64 k per stage, the MFMA waves = 4 row quarters, no K split (level 2: 4096 rows, K = 512).  Both: 8 stages of 32 KB.
-template <bool PAIR, bool TALL>
+// FORM 0: 128 rows x 128 k per stage, the MFMA waves = 2 row halves (64 rows) x 2 K halves (level 3: 1024 rows, K = 1024: 8 stages of 32 KB);
+// FORM 1: 256 rows x 64 k per stage, the MFMA waves = 4 row quarters (64 rows), no K split (level 2: 4096 rows, K = 512: 8 stages of 32 KB);
+// FORM 2: 64 rows x 128 k per stage, the MFMA waves = 2 row tiles (32 rows) x 2 K halves (middle level: 256 rows, K = 2048: 16 stages of 16 KB).
+template <bool PAIR, int FORM>
 struct WideCfg {
-    static constexpr int BM = TALL ? 256 : 128, BK = TALL ? 64 : 128, THREADS = 512, TNT = PAIR ? 2 : 1, P = HD_WIDE_P;   // 4 MFMA waves + 4 staging waves; stages in flight
-    static constexpr int UPR = BK / 8, RG = 256 / UPR;           // 16-byte units per staged row; rows covered by the 256 staging threads per pass (8 passes)
-    static constexpr int KSP = TALL ? 1 : 2, RW = 4 / KSP;       // K halves and row parts of the MFMA waves
-    static constexpr int TPRW = 256 / BM;                        // threads per row of the statistics merge
+    static constexpr int BM = FORM == 1 ? 256 : (FORM == 2 ? 64 : 128), BK = FORM == 1 ? 64 : 128, THREADS = 512, TNT = PAIR ? 2 : 1, P = HD_WIDE_P;   // 4 MFMA waves + 4 staging waves; stages in flight
+    static constexpr int UPR = BK / 8, RG = 256 / UPR;           // 16-byte units per staged row; rows covered by the 256 staging threads per pass
+    static constexpr int UPT = BM * UPR / 256;                   // passes = units per staging thread and stage (8, 8, 4)
+    static constexpr int KSP = FORM == 1 ? 1 : 2, RW = 4 / KSP;  // K halves and row parts of the MFMA waves
+    static constexpr int MTW = FORM == 2 ? 1 : 2;                // 32-row tiles per MFMA wave
+    static constexpr int TPRW = 256 / BM;                        // threads per row of the statistics merge (2, 1, 4)
     static constexpr int AROW = BK * 2 + 16;                     // bytes per staged row (+ 16 B pad)
     static constexpr int A_BUF = BM * AROW;
     static constexpr int A_OFF = 0, STATS_OFF = 2 * A_BUF, GB_OFF = STATS_OFF + BM * 8;   // + 2 K floats (LayerNorm form)
     static constexpr int PB = HD_WIDE_PB;                        // stages of weight fragments in flight per MFMA wave
 };
 
-// 0: not a shape of this kernel; 1: the 128-row form; 2: the 256-row form
+// 0: not a shape of this kernel; 1: the 128-row form (FORM 0); 2: the 256-row form (FORM 1); 3: the 64-row form (FORM 2)
 template <bool PAIR>
 inline int wide_shape_ok(const GemmP& p) {
     const int ncols = PAIR ? p.N / 2 : p.N;
     if (p.K != p.Kp || ncols % 32 != 0 || p.film_face_stride != 0 || p.lda != p.K) return 0;
     if (p.Kp == 1024 && p.M % 128 == 0 && p.M >= 1024 && p.M <= 2048 && (p.M / 128) * (ncols / 32) >= 256) return 1;
-    static const bool no_tall = hd_env("HD_NO_WIDE_TALL") != nullptr;
+    static const bool no_tall = hd_env("HD_NO_WIDE_TALL") != nullptr, no_64 = hd_env("HD_NO_WIDE_64") != nullptr;
     if (!no_tall && p.Kp == 512 && p.M % 256 == 0 && p.M >= 4096 && (p.M / 256) * (ncols / 32) >= 256 && (p.M / 256) * (ncols / 32) <= 512) return 2;
+    if (!no_64 && p.Kp == 2048 && p.M % 64 == 0 && (p.M / 64) * (ncols / 32) >= 256 && (p.M / 64) * (ncols / 32) <= 512) return 3;
     return 0;
 }
+inline int wide_form_rows(int form) { return form == 1 ? 128 : (form == 2 ? 256 : 64); }
 
 // the statistics merge takes up to 16 partials per thread: 32 per row in the 128-row form (two threads per row), 16 in the 256-row form
 template <bool PAIR>
 inline bool wide_stats_ok(const GemmP& p) {
     const int form = wide_shape_ok<PAIR>(p);
-    return form != 0 && p.stats_np >= 1 && p.stats_np <= (form == 1 ? 32 : 16) && p.stats_np * p.stats_cnt == p.K;
+    return form != 0 && p.stats_np >= 1 && p.stats_np <= (form == 1 ? 32 : (form == 2 ? 16 : 64)) && p.stats_np * p.stats_cnt == p.K;
 }
 
 #ifdef HD_STAMPS     // tools/deep_bench: per-stage stamps of workgroup 0's first staging wave (role 1) and first MFMA wave (role 0), slots 4096 + role * 64 + 4 stage + k
@@ -83,9 +88,9 @@ inline bool wide_stats_ok(const GemmP& p) {
 #else
 #define HD_WSTAMP(role, s, k) do { } while (0)
 #endif
-template <bool LN, class EP, bool PAIR, bool TALL, int NST>
+template <bool LN, class EP, bool PAIR, int FORM, int NST>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
-    typedef WideCfg<PAIR, TALL> C;
+    typedef WideCfg<PAIR, FORM> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,10 +113,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     // ---- staging roles: A unit (16 B) column q16 of rows r8 + 16 u; B fragments f = wave + 4 j -> (gate half f / 8, k-step f % 8) ----
     const int q16 = ptid % C::UPR, r8 = ptid / C::UPR;
     const unsigned short* Ap = reinterpret_cast<const unsigned short*>(p.A) + (size_t)(row0 + r8) * p.lda + q16 * 8;
-    u32x4 raw[C::P][8];
+    u32x4 raw[C::P][C::UPT];
 #define HD_WIDE_LOAD(s)                                                                                            \
     {                                                                                                               \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                               \
+        _Pragma("unroll") for (int u = 0; u < C::UPT; ++u)                                                          \
             raw[(s) % C::P][u] = *reinterpret_cast<const u32x4*>(Ap + (size_t)(C::RG * u) * p.lda + (HD_WIDE_ASTAGE(s)) * C::BK);    \
     }
     if (producer) {
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     HD_STAMP(1);
 
     // ---- LayerNorm: (mean, rstd) of the 128 rows from the producer's partials, FiLM row to LDS ----
-    float mu[8], rs[8];
+    float mu[C::UPT], rs[C::UPT];
     float* gb = reinterpret_cast<float*>(smem + C::GB_OFF);
     if constexpr (LN) {
       if (!producer) {                                                 // the MFMA waves have nothing to do yet: they merge the statistics and stage the FiLM row
@@ -139,20 +144,22 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
         float sm = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sm += s[i].y >= 0.f ? s[i].x : 0.f;
-        if (C::TPRW == 2) sm += dpp_mov<0xB1>(sm);                  // lane ^ 1: the row's other thread
+        if (C::TPRW >= 2) sm += dpp_mov<0xB1>(sm);                  // lane ^ 1, lane ^ 2: the row's other threads
+        if (C::TPRW == 4) sm += dpp_mov<0x4E>(sm);
         const float inv_np = 1.0f / (float)np, cnt = (float)p.stats_cnt;
         const float mean = sm * inv_np;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { const float d = s[i].x - mean; q += s[i].y >= 0.f ? fmaf(cnt * d, d, s[i].y) : 0.f; }
-        if (C::TPRW == 2) q += dpp_mov<0xB1>(q);
+        if (C::TPRW >= 2) q += dpp_mov<0xB1>(q);
+        if (C::TPRW == 4) q += dpp_mov<0x4E>(q);
         const float var = q * (inv_np / cnt);
         if (part == 0) reinterpret_cast<float2*>(smem + C::STATS_OFF)[rl] = make_float2(mean, __frsqrt_rn(var + p.ln_eps));
       }
         __syncthreads();
         if (producer)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < C::UPT; ++u) {
             float2 st = reinterpret_cast<const float2*>(smem + C::STATS_OFF)[r8 + C::RG * u];
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st.x), "+v"(st.y));      // two registers of their own (LdF32LN_T::unit_stats)
             mu[u] = -st.x * st.y; rs[u] = st.y;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
             const f4v g0 = *(lds_f4*)(gl + k), g1 = *(lds_f4*)(gl + k + 4), b0 = *(lds_f4*)(gl + p.K + k), b1 = *(lds_f4*)(gl + p.K + k + 4);
             const f32x2_t g[4] = {{g0.x, g0.y}, {g0.z, g0.w}, {g1.x, g1.y}, {g1.z, g1.w}}, b[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < C::UPT; ++u) {
                 const u32x4 w = raw[s % C::P][u];
                 const f32x2_t r2 = {rs[u], rs[u]}, m2 = {mu[u], mu[u]};
                 u32x4 o;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < C::UPT; ++u) {
                 *reinterpret_cast<u32x4*>(sA + C::RG * u * C::AROW) = raw[s % C::P][u];
                 if (ls >= 0) {
                     raw[ls % C::P][u] = *reinterpret_cast<const u32x4*>(Ap + (size_t)(C::RG * u) * p.lda + (HD_WIDE_ASTAGE(ls)) * C::BK);
@@ -222,6 +229,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     }
 #undef HD_WIDE_LOAD
     constexpr int NM = C::KSP == 1 ? 2 : 1;                             // row tiles a MFMA wave finishes: both of its own (no K split) / one after the exchange
+    const bool finisher = producer ? false : (C::MTW == 2 || kh == 0);  // one tile per wave and two K halves: K half 0 finishes it
     f32x16_t mine[NM][C::TNT];
     if (!producer) {
     // the MFMA waves take their weight fragments straight from global memory (packed in fragment order: one coalesced 1 KiB load per
@@ -241,29 +249,29 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     for (int d = 0; d < C::PB; ++d) HD_WIDE_BLOAD(d);
     asm volatile("s_barrier" ::: "memory");                             // stage 0 is in LDS
     HD_STAMP(2);
-    f32x16_t acc[2][C::TNT];
+    f32x16_t acc[C::MTW][C::TNT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < C::MTW; ++mt)
 #pragma unroll
         for (int t = 0; t < C::TNT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.f;
-    const int a_lane_off = (rh * 64 + (lane & 31)) * C::AROW + (lane >> 5) * 16 + kh * 4 * 32;
+    const int a_lane_off = (rh * 32 * C::MTW + (lane & 31)) * C::AROW + (lane >> 5) * 16 + kh * 4 * 32;
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         HD_WSTAMP(0, s, 0);
         const char* sA = smem + C::A_OFF + (s & 1) * C::A_BUF + a_lane_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(sA + j * 32), a1 = *reinterpret_cast<const bf16x8_t*>(sA + 32 * C::AROW + j * 32);
+            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(sA + j * 32), a1 = *reinterpret_cast<const bf16x8_t*>(sA + (C::MTW == 2 ? 32 : 0) * C::AROW + j * 32);
 #pragma unroll
             for (int t = 0; t < C::TNT; ++t) {
                 const bf16x8_t b = __builtin_bit_cast(bf16x8_t, breg[s % C::PB][j][t]);
 #ifdef HD_WIDE_NOMMA                                                       // what-if (tools/deep_bench): no MFMAs, the fragments are still read
-                acc[0][t][0] += __builtin_bit_cast(f32x4_wi, a0)[0] + __builtin_bit_cast(f32x4_wi, b)[0]; acc[1][t][0] += __builtin_bit_cast(f32x4_wi, a1)[1];
+                acc[0][t][0] += __builtin_bit_cast(f32x4_wi, a0)[0] + __builtin_bit_cast(f32x4_wi, b)[0]; acc[C::MTW - 1][t][0] += __builtin_bit_cast(f32x4_wi, a1)[1];
 #else
                 acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][t], 0, 0, 0);
+                if constexpr (C::MTW == 2) acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][t], 0, 0, 0);
 #endif
             }
         }
@@ -280,25 +288,33 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     HD_STAMP(3); HD_STAMP(4);
 
     if constexpr (C::KSP == 2) {
-        // ---- the two K halves meet: wave (rh, kh) takes over row tile kh of its row half and gets the partner's partial of it ----
+        // ---- the two K halves meet: with two row tiles per wave, wave (rh, kh) takes over row tile kh of its row half and gets the partner's partial of it;
+        //      with one, K half 1 hands its tile to K half 0 ----
         float* xch = reinterpret_cast<float*>(smem);                   // [wave][TNT][16][64]: the staging buffers are dead (the loop ended with a barrier)
 #pragma unroll
         for (int t = 0; t < C::TNT; ++t) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                xch[((wave * C::TNT + t) * 16 + i) * 64 + lane] = kh ? acc[0][t][i] : acc[1][t][i];      // the tile the partner keeps
-                mine[0][t][i] = kh ? acc[1][t][i] : acc[0][t][i];
+                if constexpr (C::MTW == 2) {
+                    xch[((wave * C::TNT + t) * 16 + i) * 64 + lane] = kh ? acc[0][t][i] : acc[1][t][i];      // the tile the partner keeps
+                    mine[0][t][i] = kh ? acc[1][t][i] : acc[0][t][i];
+                } else {
+                    if (kh) xch[((wave * C::TNT + t) * 16 + i) * 64 + lane] = acc[0][t][i];
+                    mine[0][t][i] = acc[0][t][i];
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int partner = rh + 2 * (1 - kh);
+        const int partner = rh + C::RW * (1 - kh);
+        if (C::MTW == 2 || kh == 0) {
 #pragma unroll
-        for (int t = 0; t < C::TNT; ++t)
+            for (int t = 0; t < C::TNT; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float o = xch[((partner * C::TNT + t) * 16 + i) * 64 + lane];
-                mine[0][t][i] = kh ? o + mine[0][t][i] : mine[0][t][i] + o;         // K half 0 + K half 1, whoever adds
-            }
+                for (int i = 0; i < 16; ++i) {
+                    const float o = xch[((partner * C::TNT + t) * 16 + i) * 64 + lane];
+                    mine[0][t][i] = kh ? o + mine[0][t][i] : mine[0][t][i] + o;         // K half 0 + K half 1, whoever adds
+                }
+        }
     } else {
 #pragma unroll
         for (int m = 0; m < NM; ++m)
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
         float* rs = reinterpret_cast<float*>(smem + T1_OFF + 2 * C::BM * 32 * 4);  // [BM / S][32] row sums (over dead staging / statistics / FiLM rows)
         const int S = p.side, ls = 31 - __builtin_clz(S), HW = p.hw;
         float* wx = rs + (C::BM >> ls) * 32;                                // [2][10][32] taps + bias of both halves
-        if (!producer) {
+        if (finisher) {
 #pragma unroll
             for (int t = 0; t < C::TNT; ++t) {
                 const float b1 = p.bias[(t ? tile1 : tile0) * 32 + (lane & 31)];
@@ -323,11 +339,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
                 for (int m = 0; m < NM; ++m)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const int r = rh * 64 + (C::KSP == 2 ? kh : m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                        const int r = rh * 32 * C::MTW + (C::MTW == 1 ? 0 : (C::KSP == 2 ? kh : m)) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                         t1[(t * C::BM + r) * 32 + (lane & 31)] = mine[m][t][i] + b1;
                     }
             }
-        } else if (pw == 0) {                                               // one staging wave fetches the taps: half-wave 0 holds half a, half-wave 1 half b
+        } else if (producer && pw == 0) {                                   // one staging wave fetches the taps: half-wave 0 holds half a, half-wave 1 half b
             const int hb = (tid >> 5) & 1, jj = tid & 31, ce = tile0 * 32 + jj + hb * (p.N >> 1);
 #pragma unroll
             for (int t = 0; t < 9; ++t) wx[(hb * 10 + t) * 32 + jj] = p.dw_w[(size_t)t * p.N + ce];
@@ -374,30 +390,34 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmP p) {
     } else {
         const int ncols = PAIR ? (p.N >> 1) : p.N;
         const int col = tile0 * 32 + (lane & 31);
+        if (finisher)
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            const int rtile = row0 + rh * 64 + (C::KSP == 2 ? kh : m) * 32;
+            const int rtile = row0 + rh * 32 * C::MTW + (C::MTW == 1 ? 0 : (C::KSP == 2 ? kh : m)) * 32;
             tile_epilogue_mfma<true, PAIR, EP>(p, mine[m][0], mine[m][PAIR ? 1 : 0], rtile + 4 * (lane >> 5), col, ncols, tile0, lane);
         }
         HD_STAMP(5);
     }
 }
 
-template <bool LN, class EP, bool PAIR, bool TALL>
+template <bool LN, class EP, bool PAIR, int FORM, int NST>
 inline hipError_t launch_gemm_wide_inst(const GemmP& p, hipStream_t s) {
-    typedef WideCfg<PAIR, TALL> C;
+    typedef WideCfg<PAIR, FORM> C;
     const int ncols = PAIR ? p.N / 2 : p.N;
-    const int smem = C::GB_OFF + (LN ? 2 * p.Kp * 4 : 0);
+    int smem = C::GB_OFF + (LN ? 2 * p.Kp * 4 : 0);
+    const int epi = 32768 + 2 * C::BM * 32 * 4 + (C::BM / 2) * 32 * 4 + 2 * 10 * 32 * 4;     // exchange area, T1 tiles, row sums (faces of >= 2 x 2), taps: the depthwise epilogue's LDS
+    if (EP::kTile && smem < epi) smem = epi;
     static std::atomic<unsigned long long> granted{0};
-    { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&gemm_wide_kernel<LN, EP, PAIR, TALL, 8>), 160 * 1024, granted); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL((gemm_wide_kernel<LN, EP, PAIR, TALL, 8>), dim3(p.M / C::BM, ncols / 32, 1), dim3(C::THREADS), smem, s, p);
+    { const hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(&gemm_wide_kernel<LN, EP, PAIR, FORM, NST>), 160 * 1024, granted); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL((gemm_wide_kernel<LN, EP, PAIR, FORM, NST>), dim3(p.M / C::BM, ncols / 32, 1), dim3(C::THREADS), smem, s, p);
     return hipGetLastError();
 }
 template <bool LN, class EP, bool PAIR>
 inline hipError_t launch_gemm_wide(const GemmP& p, hipStream_t s) {
-    const int form = wide_shape_ok<PAIR>(p);                            // both forms: K / BK = 8 stages
-    if (form == 1) return launch_gemm_wide_inst<LN, EP, PAIR, false>(p, s);
-    if (form == 2) return launch_gemm_wide_inst<LN, EP, PAIR, true>(p, s);
+    const int form = wide_shape_ok<PAIR>(p);
+    if (form == 1) return launch_gemm_wide_inst<LN, EP, PAIR, 0, 8>(p, s);          // K / BK stages
+    if (form == 2) return launch_gemm_wide_inst<LN, EP, PAIR, 1, 8>(p, s);
+    if (form == 3) return launch_gemm_wide_inst<LN, EP, PAIR, 2, 16>(p, s);
     return hipErrorInvalidValue;
 }
 

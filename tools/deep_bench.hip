@@ -91,13 +91,16 @@ void run(const char* name, int M, int K, int N, bool ln, int side = 0) {
     };
     auto launch = [&](const GemmP& q) -> hipError_t {
         if constexpr (WIDE) return launch_gemm_wide<std::is_same<LD, LdF32LN_T<false>>::value, EP, PAIR>(q, s);
+        else if (K == 2048) return launch_skinny_auto<1, 2, PAIR, LD, EP>(q, s);
         else return launch_gemm_deep<LD, EP, PAIR>(q, s);
     };
-    if (WIDE ? !wide_shape_ok<PAIR>(base(0)) : !deep_shape_ok<PAIR>(base(0))) { printf("%s: shape not taken by this kernel\n", name); return; }
+    if (WIDE ? !wide_shape_ok<PAIR>(base(0)) : (K != 2048 && !deep_shape_ok<PAIR>(base(0)))) { printf("%s: shape not taken by this kernel\n", name); return; }
     if constexpr (WIDE) {   // same inputs through the deep kernel first: the two outputs side by side
         const size_t n = (size_t)M * ncols;
         GemmP q = base(0);
-        CK((launch_gemm_deep<LD, EP, PAIR>(q, s))); CK(hipStreamSynchronize(s));
+        if (K == 2048) { CK((launch_skinny_auto<1, 2, PAIR, LD, EP>(q, s))); }     // middle level: the reference is the 64-row skinny tile the library uses there
+        else { CK((launch_gemm_deep<LD, EP, PAIR>(q, s))); }
+        CK(hipStreamSynchronize(s));
         std::vector<unsigned short> h16(n); std::vector<float> h32(n);
         CK(hipMemcpy(h16.data(), out16, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h32.data(), out, n * 4, hipMemcpyDeviceToHost));
         CK(hipMemset(out16, 0, n * 2)); CK(hipMemset(out, 0, n * 4));
@@ -138,6 +141,10 @@ int main(int argc, char** argv) {
         run<LdBF16Plain, EpGateBF16, true, true>("WHAT-IF bf16 -> conv4 -> gate (WIDE, no LayerNorm)", 1024, 1024, 2048, false);
         run<LdF32LN_T<false>, EpDwGate, true>("LN -> conv1 -> depthwise -> gate (pair8)", 1024, 1024, 2048, true, 4);
         run<LdF32LN_T<false>, EpDwGate, true, true>("LN -> conv1 -> depthwise -> gate (WIDE)", 1024, 1024, 2048, true, 4);
+        run<LdF32LN_T<false>, EpGateBF16, true>("LN -> conv4 -> gate (skinny 64 rows)", 256, 2048, 4096, true);
+        run<LdF32LN_T<false>, EpDwGate, true>("LN -> conv1 -> depthwise -> gate (skinny 64 rows)", 256, 2048, 4096, true, 2);
+        run<LdF32LN_T<false>, EpGateBF16, true, true>("LN -> conv4 -> gate (WIDE, 64 rows)", 256, 2048, 4096, true);
+        run<LdF32LN_T<false>, EpDwGate, true, true>("LN -> conv1 -> depthwise -> gate (WIDE, 64 rows)", 256, 2048, 4096, true, 2);
         run<LdF32LN_T<false>, EpGateBF16, true>("LN -> conv4 -> gate (pair8)", 4096, 512, 1024, true);
         run<LdF32LN_T<false>, EpGateBF16, true, true>("LN -> conv4 -> gate (WIDE, 256 rows)", 4096, 512, 1024, true);
         run<LdBF16Plain, EpResidF32, false>("bf16 -> conv5 -> residual (deep)", 4096, 512, 512, false);
