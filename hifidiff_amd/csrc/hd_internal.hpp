@@ -631,7 +631,7 @@ void add_gemm(hd_ctx* c, std::vector<Op>& prog, const std::string& name, GemmP p
     Chain* chp = c->ch;
     auto gp = std::make_shared<GemmP>(p);
     op.gemm = gp;
-    op.skinny_affine = p.xcd_tile_affine && (t128 & 16) == 0 && t128 != 0 && t128 != 1 && t128 != 4;     // modes 0/1/4 are the tall kernel
+    op.skinny_affine = p.xcd_tile_affine && (t128 & 48) == 0 && t128 != 0 && t128 != 1 && t128 != 4;     // bit 16 = deep kernel, bit 32 = wide kernel (launch_tile routes those elsewhere); base modes 0/1/4 are the tall kernel
     op.run = [c, chp, gp, lk, ek, t128, film](hipStream_t s) mutable -> hipError_t {
                         if (film && gp->film == nullptr) {        // denoiser FiLM rows live in the (re-allocatable) table
                             GemmP q = *gp;

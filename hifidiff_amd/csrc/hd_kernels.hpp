@@ -448,8 +448,6 @@ static __global__ void sched_step_direct_kernel(float* __restrict__ x, const flo
     x[i] = r;
 }
 
-// ------------------------------------------------------------------------------- pooling / layout
-// channels-last fp32 -> NCHW fp32 (priors handed out by hd_fpg)
 // A persistent stage of this call gave up a hand-off wait (abort word set): everything computed since is invalid, so the
 // call's result buffer is filled with NaN -- the caller sees the failure in the very tensors it gets back, whatever it does
 // with the return code (hd_check() reports it after a synchronisation).  One launch per hd_eps / hd_sample call.
@@ -459,6 +457,8 @@ static __global__ void poison_if_abort_kernel(const unsigned* __restrict__ abort
     if (i < n) out[i] = __builtin_nanf("");
 }
 
+// ------------------------------------------------------------------------------- pooling / layout
+// channels-last fp32 -> NCHW fp32 (priors handed out by hd_fpg)
 static __global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;

@@ -162,14 +162,20 @@ int build_denoiser_program(hd_ctx* c) {
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
                 r.phase_limit = (c->stage_limit_first < 0 || c->stage_limit_first == first) ? c->xcd_phase_limit : 0;
                 r.force_global = c->xcd_force_global; r.test_abort = c->stage_test_abort;
-                return run_xcd2_stage(l3 ? 1024 : 512, r, s);
+                const hipError_t e = run_xcd2_stage(l3 ? 1024 : 512, r, s);
+                if (e == hipSuccess) return e;
+                (void)hipGetLastError();                      // refused launch (LDS / CU budget of this device or tenant): nothing ran -> the K-split form, then the per-GEMM launches
+                c->xcd2_on = false;
             }
             if (c->xcd_ok && c->xcd_on && c->chains.size() == 1 && c->film_face_stride == 0) {
                 XStageP r = sp;
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
                 r.phase_limit = (c->stage_limit_first < 0 || c->stage_limit_first == first) ? c->xcd_phase_limit : 0;
                 r.force_global = c->xcd_force_global; r.test_abort = c->stage_test_abort;
-                return run_xcd_stage(l3 ? 1024 : 512, r, s);
+                const hipError_t e = run_xcd_stage(l3 ? 1024 : 512, r, s);
+                if (e == hipSuccess) return e;
+                (void)hipGetLastError();                      // as the face stages below: a refused launch is recoverable
+                c->xcd_on = false;
             }
             for (auto& o : *sub) { const hipError_t e = o.run(s); if (e != hipSuccess) return e; }
             return hipSuccess;
@@ -1178,7 +1184,7 @@ int hd_set_option(hd_ctx* c, const char* key, int value) {
     else if (k == "face") c->face_on = value != 0;
     else if (k == "face_block_limit") c->face_block_limit = value;
     else if (k == "stage_limit_first") c->stage_limit_first = value;
-    else if (k == "stage_test_abort") c->stage_test_abort = value;   // fault injection: 1..: XCD stages, group 0 gives up its wait for phase value - 1; 1000 + b: face stages, face 0, block b
+    else if (k == "stage_test_abort") c->stage_test_abort = value;   // fault injection: 1..: XCD stages, group 0 gives up its wait for phase value - 1; 1000 + b: face stages, face 0, block b; 2000 + p: a loader wave of hd_xcd2.hpp, phase p
     else HD_FAIL(c, HD_ERR_INVALID, "unknown option %s", key);
     c->graphs_valid = false;                               // captured graphs hold the old choice
     for (auto& kv : c->ws_cache) kv.second.graphs_valid = false;

@@ -69,7 +69,7 @@ struct X2StageP {
     const float* film; float ln_eps;
     unsigned short* outg16; const float *gate_c, *gate_s, *add_src;
     unsigned *flags, *hello, *gstate;      // [8 groups][128] | [8][32] | [8][32]
-    unsigned *tmo, *abort_dev; int test_abort;
+    unsigned *tmo, *abort_dev; int test_abort;           // test_abort: n in 1..: compute waves of group 0 give up the wait for phase n - 1; 2000 + p: loader 0 of group 0 before LayerNorm phase p
     int phase_limit, force_global;
 #ifdef HD_STAMPS
     unsigned long long* stamps;            // [phase][workgroup][8] of compute wave 0

@@ -33,7 +33,7 @@
 // Hand-off protocol: MI355X_MICROARCH.md "Valid forms" row 1 per WAVE -- stores, the storing wave's s_waitcnt vmcnt(0),
 // its flag store; consumers poll with sc1 loads and read the payload with sc1 loads only.  Inside one XCD (checked at run
 // time, HW_REG_XCC_ID handshake) payload and flag stores are plain, otherwise write-through.  Every spin is bounded;
-// giving up raises the abort words (hd_xcd.hpp) and every wave of the workgroup leaves.
+// giving up -- by a compute wave or by a loader wave -- raises the abort words (hd_xcd.hpp) and every wave of the workgroup leaves.
 #pragma once
 #include "hd_xcd.hpp"
 
@@ -186,6 +186,8 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
         unsigned cum = 0;                                             // ring fragments of all earlier steps (every loader counts the same)
         const unsigned a_landed = x2_lds_addr(&L.landed[lw]), a_cons = x2_lds_addr(&L.consumed[0]), a_gbdone = x2_lds_addr(&L.gbdone[0]);
         int ln_seen = 0;
+        // fault injection (hd_set_option "stage_test_abort" = 2000 + ph): loader 0 of group 0 gives up its wait for the gain | bias row of LayerNorm phase ph
+        auto loader_inject = [&](int ph) { return p.test_abort == 2000 + ph && group == 0; };
         for (int ph = 0; ph < P_run; ++ph) {
             const int blk = ph / 5, q = ph - 5 * blk;
             const bool pair = (q == 0 || q == 3);
@@ -195,9 +197,9 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
                 // the gain | bias row: free once every compute wave has finished the K loop of the previous LayerNorm phase
                 for (unsigned spins = 0;; ++spins) {
                     const unsigned v = lane < K::NCW ? x2_lds_ld(a_gbdone + 4 * lane) : 0xffffffffu;
-                    if (__all(v >= (unsigned)ln_seen)) break;
+                    if (!loader_inject(ph) && __all(v >= (unsigned)ln_seen)) break;
                     if (x2_lds_ldu(a_abort)) return;
-                    if (spins > XS_SPINS) { x2_lds_st(a_abort, 1u); return; }
+                    if (spins > XS_SPINS || loader_inject(ph)) { x2_give_up(a_abort, p.abort_dev, p.tmo, 0x700u + (unsigned)ph, lane); return; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 const float* f = p.film + L.blk[blk].film_off + (q == 3 ? 2 * C : 0);     // [bias | gain] of this LayerNorm
@@ -236,7 +238,7 @@ __global__ __launch_bounds__((X2Cfg<C, HW>::THREADS)) void xcd2_stage_kernel(con
                             if (lane == 0) x2_lds_st(a_landed, issued);
                         }
                         if (x2_lds_ldu(a_abort)) return;
-                        if (spins > XS_SPINS) { x2_lds_st(a_abort, 1u); return; }
+                        if (spins > XS_SPINS) { x2_give_up(a_abort, p.abort_dev, p.tmo, 0x700u + (unsigned)ph, lane); return; }
                         __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll

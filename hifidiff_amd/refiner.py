@@ -228,7 +228,9 @@ class _Engine:
         """Where the reference's loop would have raised synchronously (test_refiner.py:89-91): forward() / sample() only enqueue
         work, and a persistent stage launch that has to give up (another tenant kept one of its workgroups off the GPU) fills the
         result of THAT call with NaN on the device.  This synchronises the current stream and raises RuntimeError once for such
-        a call; the context has then switched itself to one launch per GEMM and the next call is valid again."""
+        a call; the context has then switched itself to one launch per GEMM and the next call is valid again.  EVERY call issued
+        between the stage giving up and this check may be poisoned (a call enqueued behind the failing one runs its stages before
+        the host has seen the word): the error is raised once and names the first failure."""
         if self.ctx is None:
             return
         if synchronize:

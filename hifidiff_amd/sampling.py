@@ -38,13 +38,15 @@ def ddim_sample_eager_unconditional(model, latents, scheduler, num_inference_ste
 
 
 @torch.no_grad()
-def sample(model, latents, cr_face, cr_latent, scheduler, noise=None, seed=0, prepare=True, check=False):
+def sample(model, latents, cr_face, cr_latent, scheduler, noise=None, seed=0, prepare=True, check=True):
     """Whole loop on the GPU: returns the final latents (a new tensor).
 
     noise: optional [n_steps, B, 4, L, L] tensor of z (DDPM); None -> device Philox(seed).
     For the unconditional `Denoiser` pass cr_face = cr_latent = None.
-    The call only enqueues work.  check=True synchronises the stream afterwards and raises RuntimeError if a persistent
-    stage launch gave up during the loop (the returned latents are NaN in that case either way: `model.check()`)."""
+    check=True (the default): ONE stream synchronisation after the whole loop (not per step), then RuntimeError if a persistent
+    stage launch gave up during it -- where the reference's loop would have raised (test_refiner.py:89-91), so that the last batch
+    of a val_loop cannot end with rc 0 and NaN images.  check=False only enqueues the work (the returned latents are NaN in the
+    failing case either way; `model.check()` reports it later).  bench.py times the loop with its own synchronisation."""
     e = model.engine
     e.ensure(latents.device)
     if latents.shape[0] == 0:                              # empty batch: nothing to sample

@@ -67,13 +67,17 @@ class _Base:
     def coefficient_table(self):
         """(timesteps [n] fp32, coef [n,7] fp32) for hd_sample: see hd_schedule in include/hifidiff_hip.h.
         The table depends on the schedule only (1000 x a dozen fp32 scalar operations in diffusers' order: 12 ms of host time),
-        so it is kept until the timesteps or the clipping change -- like the FiLM table of the schedule inside hd_sample."""
-        ts = self.timesteps.tolist()
-        key = (tuple(ts), self.num_inference_steps, self.clip_sample, self.clip_sample_range)
+        so it is kept until anything `_coef` reads changes (timesteps, step counts, clipping, the alpha tables) -- like the FiLM
+        table of the schedule inside hd_sample.  The two tensors are shared with the cache: read-only for the caller."""
+        ts = [int(t) for t in (self.timesteps.tolist() if hasattr(self.timesteps, "tolist") else self.timesteps)]
+        ac, fa = self.alphas_cumprod, self.final_alpha_cumprod
+        # everything _coef reads: the schedule, the clipping, and the alpha tables (identity + in-place version of the tensors)
+        key = (tuple(ts), self.num_inference_steps, self.num_train_timesteps, self.clip_sample, self.clip_sample_range,
+               id(ac), getattr(ac, "_version", 0), float(fa))
         hit = getattr(self, "_coef_cache", None)
         if hit is None or hit[0] != key:
             hit = (key, torch.tensor(ts, dtype=torch.float32),
-                   torch.tensor([self._coef(int(t)) for t in ts], dtype=torch.float32).reshape(len(ts), 7))
+                   torch.tensor([self._coef(t) for t in ts], dtype=torch.float32).reshape(len(ts), 7))
             self._coef_cache = hit
         return hit[1], hit[2]
 

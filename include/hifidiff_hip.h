@@ -163,7 +163,10 @@ int hd_get_option(hd_ctx* ctx, const char* key);
  * returns HD_ERR_HIP once for such a call (hd_last_error() names the stage and phase) and switches the context to one
  * launch per GEMM; the next hd_eps / hd_sample performs the same check on entry.  0 when nothing failed.
  * Fault injection for tests: hd_set_option(ctx, "stage_test_abort", n): n in 1..: group 0 of every XCD-local stage gives up
- * its wait for phase n - 1; 1000 + b: face 0 of every face-cluster stage gives up the pool wait of block b; 0: off. */
+ * its wait for phase n - 1; 1000 + b: face 0 of every face-cluster stage gives up the pool wait of block b; 2000 + p: the first
+ * loader wave of group 0 of every autonomous-wave stage (hd_xcd2.hpp) gives up its wait before LayerNorm phase p (p = 0 or 3 mod 5);
+ * 0: off.  Every call issued between a stage giving up and the check that reports it may be NaN-poisoned: the report names the
+ * first failure only. */
 int hd_check(hd_ctx* ctx);
 /* HIP-event time in ms of the most recent hd_sample's replay loop (0 if profiling is off) and the
  * summed duration of the GEMM launches: used by bench.py for the roofline object */

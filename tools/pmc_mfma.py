@@ -21,6 +21,19 @@ def family(k):
     m = re.search(r"naf_face_stage_kernel<(\d+), *(\d+)>", k)
     if m:
         return f"naf_face_stage<{m.group(1)},{m.group(2)}> (levels 0/1, persistent)"
+    m = re.search(r"gemm_wide_kernel<(true|false), *(?:hd::)?(Ep\w+), *(true|false), *(\d+), *(\d+)>", k)
+    if m:
+        form = {"0": "128-row", "1": "256-row", "2": "64-row"}.get(m.group(4), "form " + m.group(4))
+        return f"gemm_wide {'LN' if m.group(1) == 'true' else 'bf16'} {m.group(2)} {form} (latent 32, role-split)"
+    if "gemm_wide_kernel" in k:
+        return "gemm_wide (latent 32, role-split)"
+    if "gemm_deep" in k:
+        ld = "LN" if "LdF32LN" in k else "bf16"
+        ep = re.search(r"hd::(Ep\w+)", k)
+        return f"gemm_deep{'_pair8' if 'pair8' in k else ''} {ld} {ep.group(1) if ep else ''} (many-row)"
+    m = re.search(r"naf_strip_dwgate_kernel<(\d+), *(\d+)>", k)
+    if m:
+        return f"naf_strip_dwgate<{m.group(1)},{m.group(2)}> (latent 32, levels 0/1)"
     if "naf_chain_kernel" in k:
         return "naf_chain (levels 0/1)"
     if "hca_conv_kernel" in k:
