@@ -1124,3 +1124,19 @@ def test_latent32_strip_and_wide_kernels_against_the_launch_forms_they_replace(g
     ref = l32_oracle_eps16()
     assert rel_l2(e2[:16], ref) <= 6e-3 and rel_l2(e2[64:80], ref) <= 6e-3, (rel_l2(e2[:16], ref), rel_l2(e2[64:80], ref))
     assert max(rel_l2(e2[f], ref[f]) for f in range(16)) <= 8e-3
+
+
+def test_the_cost_of_leaving_the_benchmark_shapes_is_bounded(gpu, weights16):
+    """the fast paths are pinned to the benchmark's shapes (persistent stages: latent 16, batch <= 64; the wide / deep
+    many-row GEMMs of latent 32: its batch-64 row counts).  What leaving them costs is a number (tools/batch_sweep.py,
+    profiles/r05_batch_sweep.txt: 1.04 ms per step at batch 64, 1.64 ms at 65, 1.75 ms at 128); asserted here: the launch counts on either
+    side of the cliff, that a face at batch 65 costs at most 1.7x the batch-64 face (measured 1.55x) and that the one-launch-per-GEMM
+    program is still the better answer there: taking the batch through the persistent stages in passes of 64 would cost two batch-64
+    steps (2.08 ms) at any batch from 65 to 128, which is more than the launches take at either end of that range."""
+    import batch_sweep
+    rows = {r[0]: r for r in batch_sweep.sweep(16, (64, 65, 128), weights=weights16, n_steps=16, reps=2)}
+    assert (rows[64][1], rows[65][1], rows[128][1]) == (63, 151, 151), rows
+    per_face = {b: rows[b][3] for b in rows}
+    assert per_face[65] <= 1.7 * per_face[64], per_face
+    assert per_face[128] <= 1.0 * per_face[64], per_face           # measured 0.84x: the per-GEMM launches barely notice the row count
+    assert rows[65][2] < 2.0 * rows[64][2] and rows[128][2] < 2.0 * rows[64][2], rows      # passes of 64 would lose at both ends
