@@ -215,3 +215,39 @@ def test_incremental_build_knows_what_each_unit_includes():
         assert deps[u] == {u, "hd_dispatch.hpp", "hd_gemm.hpp", "hd_wide.hpp"}, deps[u]      # hd_wide.hpp: a GEMM kernel of the launch table, not a stage
     assert {"hd_strip.hpp", "hd_chain.hpp", "hd_stage_api.hpp"} <= deps["hd_strip.hip"] and "hd_strip.hpp" not in deps["hd_lib.hip"]
     assert set(os.path.basename(p) for p in _lib.SOURCES) >= set().union(*deps.values()) - {"hifidiff_hip.h"}
+
+
+def test_scheduler_table_cache_follows_everything_coef_reads():
+    """the coefficient table depends on alphas_cumprod, final_alpha_cumprod and num_train_timesteps too; a stale table must
+    not be served after any of them changes, and plain iterables are accepted as timesteps again."""
+    s = schedulers.DDIMScheduler(clip_sample_range=3.0)
+    s.set_timesteps(50)
+    _, c0 = s.coefficient_table()
+    s.alphas_cumprod.mul_(0.5)                                          # in place: same tensor object, new version
+    _, c1 = s.coefficient_table()
+    assert c1 is not c0 and not torch.equal(c1, c0)
+    s.final_alpha_cumprod = torch.tensor(0.9)
+    _, c2 = s.coefficient_table()
+    assert c2 is not c1 and not torch.equal(c2[-1], c1[-1])             # the last step reads final_alpha_cumprod
+    s.timesteps = [int(t) for t in s.timesteps[:5]]                     # a list, not a tensor
+    ts, c3 = s.coefficient_table()
+    assert ts.numel() == 5 and torch.equal(c3, c2[:5])
+
+
+def test_bench_latency_floor_adds_up_its_terms():
+    """roofline.latency_floor_ms = dependent launches x boundary + in-launch hand-offs x hand-off + weights / stream rate
+    (or the MFMA time at peak if longer), every term with the profiles/ file it was measured in."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)                                          # no GPU call at import
+    r = b.latency_floor(16, 63, b.SURVEY_WEIGHT_BYTES[16], b.SURVEY_FLOPS_PER_FACE_STEP[16] * 64)
+    t = r["latency_floor_terms_us"]
+    assert t["inlaunch_handoffs"] == 92 and abs(t["launch_boundaries"] - 63 * 2.21) < 0.06 and abs(t["handoffs"] - 92 * 0.8) < 0.06
+    assert abs(t["weight_stream_or_mfma"] - 722.66e6 / 6.5e12 * 1e6) < 0.06
+    assert abs(r["latency_floor_ms"] - (63 * 2.21 + 92 * 0.8 + 111.18) * 1e-3) < 1e-3
+    assert b.inlaunch_handoffs(16, 151) == 0 and b.inlaunch_handoffs(32, 151) == 0
+    r32 = b.latency_floor(32, 151, b.SURVEY_WEIGHT_BYTES[32], b.SURVEY_FLOPS_PER_FACE_STEP[32] * 64)
+    assert abs(r32["latency_floor_terms_us"]["weight_stream_or_mfma"] - 8.2917e9 * 64 / 2.5e15 * 1e6) < 0.06      # MFMA time at peak is the longer one
+    for src in r["latency_floor_sources"].values():
+        assert os.path.exists(os.path.join(ROOT, src[1])), src
