@@ -240,7 +240,7 @@ def cpu_baseline(P, latent, n_diff, full_config1=True):
     return out
 
 
-def measure_config3(dev, passes=3):
+def measure_config3(dev, passes=3, reuse=None):
     """BASELINE configs[3] (test_refiner.py:67,162: latent_res = image_res // 8 = 32): batch 64, 32->256 px, 250-step DDIM, one GPU.
     One warm-up pass (captures the graphs, builds the FiLM table) and `passes` timed passes between synchronisations, prologue included,
     like the headline; run AFTER the headline's timed region, reported as `secondary` in the same JSON line."""
@@ -248,7 +248,7 @@ def measure_config3(dev, passes=3):
     from hifidiff_amd.refiner import FacialRefiner
     import numpy as np
     L, B, n_diff = 32, 64, 250
-    P32 = synth.refiner_state_dict(L)
+    P32 = synth.refiner_state_dict(L, reuse=reuse)           # the weights that do not depend on the latent side are the headline's own tensors
     m = FacialRefiner(L)
     m.load_state_dict(P32)
     m.to(dev)
@@ -472,7 +472,7 @@ def main():
             "roofline": roof,
         }
         if headline and world == 1 and not a.no_secondary:    # BASELINE configs[3], after the headline's timed region; never touches `value`
-            res["secondary"] = measure_config3(dev)
+            res["secondary"] = measure_config3(dev, reuse=(P, a.latent))
         if not a.no_cpu_baseline and world == 1:              # the CPU leg is reported at N=1 only
             cb = cpu_baseline(P, a.latent, n_diff)
             res["cpu_baseline"] = {

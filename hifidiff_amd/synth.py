@@ -88,11 +88,16 @@ def make_tensor(name: str, shape, kind: str, fan_in: int, seed: int = WEIGHT_SEE
     return v.astype(np.float32).reshape(shape)
 
 
-def make_state_dict(manifest, seed: int = WEIGHT_SEED, as_torch: bool = True, only=None):
-    """name -> tensor for every entry of an arch.*_manifest (optionally a prefix filter)."""
+def make_state_dict(manifest, seed: int = WEIGHT_SEED, as_torch: bool = True, only=None, reuse=None):
+    """name -> tensor for every entry of an arch.*_manifest (optionally a prefix filter).
+    reuse = (state dict, its manifest) made with the same seed: entries whose (shape, kind, fan_in) are the same in both manifests are taken
+    from it instead of being generated again -- a tensor is a pure function of (name, shape, kind, fan_in, seed), so the values are identical."""
     out = {}
     for name, (shape, kind, fan_in) in manifest.items():
         if only is not None and not name.startswith(only):
+            continue
+        if reuse is not None and name in reuse[0] and reuse[1].get(name) == (shape, kind, fan_in):
+            out[name] = reuse[0][name]
             continue
         a = make_tensor(name, shape, kind, fan_in, seed)
         if as_torch:
@@ -102,8 +107,11 @@ def make_state_dict(manifest, seed: int = WEIGHT_SEED, as_torch: bool = True, on
     return out
 
 
-def refiner_state_dict(latent_res=16, seed: int = WEIGHT_SEED, as_torch=True):
-    return make_state_dict(arch.refiner_manifest(latent_res), seed, as_torch)
+def refiner_state_dict(latent_res=16, seed: int = WEIGHT_SEED, as_torch=True, reuse=None):
+    """reuse = (state dict, latent_res it was made for), same seed and as_torch: only the tensors whose shape depends on the latent side are generated."""
+    if reuse is not None:
+        reuse = (reuse[0], arch.refiner_manifest(reuse[1]))
+    return make_state_dict(arch.refiner_manifest(latent_res), seed, as_torch, reuse=reuse)
 
 
 def cr_state_dict(seed: int = WEIGHT_SEED, wild: bool = False):

@@ -251,3 +251,18 @@ def test_bench_latency_floor_adds_up_its_terms():
     assert abs(r32["latency_floor_terms_us"]["weight_stream_or_mfma"] - 8.2917e9 * 64 / 2.5e15 * 1e6) < 0.06      # MFMA time at peak is the longer one
     for src in r["latency_floor_sources"].values():
         assert os.path.exists(os.path.join(ROOT, src[1])), src
+
+
+def test_synthetic_weights_can_be_reused_across_latent_sides():
+    """bench.py's `secondary` (latent 32) takes every tensor whose spec does not depend on the latent side from the headline's state dict:
+    a tensor is a pure function of (name, shape, kind, fan_in, seed), so only idc_conv is generated again and the values are the same."""
+    m16, m32 = arch.refiner_manifest(16), arch.refiner_manifest(32)
+    differ = sorted(n for n in m32 if m16.get(n) != m32[n])
+    assert differ == ["denoiser.idc_conv.bias", "denoiser.idc_conv.weight"], differ
+    small = {n: m16[n] for n in list(m16)[:4] + ["denoiser.idc_conv.bias"]}
+    P16 = synth.make_state_dict(small)
+    P32 = synth.make_state_dict({n: m32[n] for n in small}, reuse=(P16, small))
+    for n in small:
+        fresh = torch.from_numpy(synth.make_tensor(n, *m32[n])).reshape(tuple(m32[n][0]))
+        assert torch.equal(P32[n], fresh), n
+        assert (P32[n] is P16[n]) == (m16[n] == m32[n]), n
