@@ -57,6 +57,11 @@ int alloc_chain(hd_ctx* c, Chain& ch) {
 
 int build_denoiser_program(hd_ctx* c);
 int get_xstage(hd_ctx* c, int first_block, int nblocks, hd_ctx::XStage** out);
+// diffusion steps per captured graph (kGraphSteps; HD_GRAPH_STEPS under HD_EXPERIMENTS=1 measures other lengths)
+static int graph_steps() {
+    static const int v = [] { const char* e = hd_env("HD_GRAPH_STEPS"); const int n = e ? atoi(e) : kGraphSteps; return n < 1 ? 1 : (n > 250 ? 250 : n); }();
+    return v;
+}
 int setup_xcd(hd_ctx* c);
 
 // Cut the batch into chains (HD_CHAINS, default 1).  Two streams of these kernels do overlap (1.6x in
@@ -1072,7 +1077,7 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
                 hipGraph_t graph = nullptr;
                 hipError_t e = hipStreamBeginCapture(ch.stream, hipStreamCaptureModeThreadLocal);
                 if (e == hipSuccess) {
-                    for (int r = 0; r < (multi ? kGraphSteps : 1) && e == hipSuccess; ++r)
+                    for (int r = 0; r < (multi ? graph_steps() : 1) && e == hipSuccess; ++r)
                         for (size_t k = 0; k < ch.program.size() && e == hipSuccess; ++k) e = ch.program[k].run(ch.stream);
                     hipError_t e2 = hipStreamEndCapture(ch.stream, &graph);
                     if (e == hipSuccess) e = e2;
@@ -1089,7 +1094,7 @@ int hd_sample(hd_ctx* c, float* x_inout, const hd_schedule* sched, const float* 
     for (auto& ch : c->chains) HIPCHECK(c, hipStreamWaitEvent(ch.stream, c->fork_ev, 0));
     {
         int i = 0;
-        for (; i + kGraphSteps <= n; i += kGraphSteps)
+        for (; i + graph_steps() <= n; i += graph_steps())
             for (auto& ch : c->chains) HIPCHECK(c, hipGraphLaunch(ch.graph_multi, ch.stream));
         for (; i < n; ++i)
             for (auto& ch : c->chains) HIPCHECK(c, hipGraphLaunch(ch.graph_exec, ch.stream));
