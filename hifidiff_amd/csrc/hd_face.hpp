@@ -13,6 +13,7 @@
 //   B  per-workgroup channel sums of the gate -> the face's pooled mean.
 // Everything else is the chain kernel's arithmetic (hd_chain.hpp): SCA GEMV on the MFMA, G * s, conv3, y, LayerNorm (two-pass,
 // fp32 statistics, bf16 value), conv4, SimpleGate, conv5, x'.  Replaces 2 launches per block (fused conv1, chain kernel).
+// The encoder's first stage also takes the intro conv as its entry (FStageP::intro_lat): own and halo image rows of x straight from the latents.
 //
 // Hand-off (MI355X_MICROARCH.md "Valid forms" row 1, placement-independent): hand-off data is stored write-through (sc1) by
 // every wave, every storing wave drains (s_waitcnt vmcnt(0)), the workgroup's barrier, ONE lane stores the workgroup's flag
@@ -106,10 +107,55 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
     const __amdgpu_buffer_rsrc_t rs_PP = __builtin_amdgcn_make_buffer_rsrc(p.pool_part, 0, p.B * K::CL * C * 4, 0x00020000);
     fs_gu32* flags = (fs_gu32*)(p.flags + face * 16);
 
-    // ---- entry: own rows of x (written by the previous launch) ----
-    for (int u = tid; u < OWN * (C / 4); u += K::THREADS) {
-        const int r = u / (C / 4), q = u - r * (C / 4);
-        *reinterpret_cast<float4*>(xt + r * K::XROW + q * 4) = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + q * 4);
+    // ---- entry: own rows of x (written by the previous launch), or -- first stage of the encoder -- the intro conv of own + halo rows ----
+    bool intro = false;
+    float* hb = reinterpret_cast<float*>(smem + K::T1_OFF);          // x of the halo image rows (above: rows 0..S-1, below: S..2S-1), until block 0's LayerNorm
+    if constexpr (C == 128 && OWN == 32) intro = p.intro_lat != nullptr;
+    if (!intro) {
+        for (int u = tid; u < OWN * (C / 4); u += K::THREADS) {
+            const int r = u / (C / 4), q = u - r * (C / 4);
+            *reinterpret_cast<float4*>(xt + r * K::XROW + q * 4) = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + q * 4);
+        }
+    }
+    if constexpr (C == 128 && OWN == 32) {
+        if (intro) {
+            // intro_conv_kernel's arithmetic (hd_kernels.hpp) for the 4 image rows this workgroup needs: wave w = image row y0 + {0, 1, -1, 2};
+            // lanes over output channels (lane, lane + 64), the lane's 72 weights in registers, the 6 x 18 x 4 latent patch in LDS (broadcast reads)
+            constexpr int S = K::S;
+            if (p.intro_advance && bid == 0 && tid == 0) p.intro_step[0] += 1;
+            float* patch = gb;                                           // [4][6][S + 2] floats: the FiLM rows land here only in block 0
+            const int y0 = kk * K::RI;
+            for (int i = tid; i < 4 * 6 * (S + 2); i += K::THREADS) {
+                const int ci = i / (6 * (S + 2)), rr = (i - ci * 6 * (S + 2)) / (S + 2), xx = i - ci * 6 * (S + 2) - rr * (S + 2);
+                const int yy = y0 - 2 + rr, x = xx - 1;
+                patch[i] = (yy >= 0 && yy < S && x >= 0 && x < S) ? p.intro_lat[((size_t)(face * 4 + ci) * S + yy) * S + x] : 0.f;
+            }
+            float wl[36][2];
+#pragma unroll
+            for (int r = 0; r < 36; ++r) { wl[r][0] = p.intro_wT[r * 128 + lane]; wl[r][1] = p.intro_wT[r * 128 + lane + 64]; }
+            const float b0 = p.intro_b[lane], b1 = p.intro_b[lane + 64];
+            __syncthreads();
+            const int dy = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? -1 : 2;      // image row y0 + dy; patch row 2 + dy is its centre
+            const bool needed = wave < 2 || (wave == 2 ? has_up : has_dn);
+            float* dst = wave < 2 ? xt + wave * S * K::XROW : hb + (wave - 2) * S * K::XROW;
+            if (needed) {
+#pragma unroll 4
+                for (int px = 0; px < S; ++px) {
+                    float a0 = b0, a1 = b1;
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const float v = patch[(ci * 6 + 1 + dy + r) * (S + 2) + px + k];
+                                a0 = fmaf(v, wl[ci * 9 + r * 3 + k][0], a0);
+                                a1 = fmaf(v, wl[ci * 9 + r * 3 + k][1], a1);
+                            }
+                    dst[px * K::XROW + lane] = a0; dst[px * K::XROW + lane + 64] = a1;
+                }
+            }
+        }
     }
     __syncthreads();
     const unsigned base = s_base;
@@ -189,7 +235,7 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
         }
     };
 
-    const int nb_run = (p.block_limit > 0 && p.block_limit < p.nblocks) ? p.block_limit : p.nblocks;
+    const int nb_run = p.block_limit < 0 ? 0 : (p.block_limit > 0 && p.block_limit < p.nblocks) ? p.block_limit : p.nblocks;
     uint4 bw[K::KS], bw2[K::KS];
     for (int blk = 0; blk < nb_run; ++blk) {
         const XBlockW& B = s_blk[blk];
@@ -231,10 +277,16 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
                 hok[hi] = r < ROWS && (up ? has_up : has_dn);
                 const int grow = up ? row0 - K::S + (r - OWN) : row0 + OWN + (r - OWN - K::S);
                 const int gr = hok[hi] ? grow : row0;
+                if (intro && blk == 0) {                               // computed at the entry (no launch wrote X)
+                    const int hr = r < ROWS ? r - OWN : 0;
 #pragma unroll
-                for (int i = 0; i < V4; ++i) {
-                    const xs_u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_X, (gr * C + 4 * l16 + 64 * i) * 4, 0, 16);
-                    hv[hi][i] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+                    for (int i = 0; i < V4; ++i) hv[hi][i] = *reinterpret_cast<const float4*>(hb + hr * K::XROW + 4 * l16 + 64 * i);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < V4; ++i) {
+                        const xs_u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_X, (gr * C + 4 * l16 + 64 * i) * 4, 0, 16);
+                        hv[hi][i] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+                    }
                 }
             }
             for (int r = wave * 4 + (lane >> 4); r < OWN; r += K::NT * 4) {
@@ -458,6 +510,19 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
         }
         if (!last) publish(base + 2u * (unsigned)blk + 2u);
         HD_FSTAMP(6);
+    }
+    if constexpr (C == 128 && OWN == 32) {
+        if (nb_run == 0) {                                           // introspection (block_limit < 0): the entry's x as the stage holds it
+            int row0e = row0, tide = tid;                            // opaque: the addresses are formed here, not at the kernel's start (hd_xcd.hpp's exit)
+            asm volatile("" : "+s"(row0e), "+v"(tide));
+            for (int u = tide; u < OWN * (C / 4); u += K::THREADS) {
+                const int r = u / (C / 4), q = u - r * (C / 4);
+                const float4 v = *reinterpret_cast<const float4*>(xt + r * K::XROW + q * 4);
+                const size_t o = (size_t)(row0e + r) * C + q * 4;
+                *reinterpret_cast<float4*>(p.X + o) = v;
+                if (p.Xb) *reinterpret_cast<uint2*>(p.Xb + o) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+            }
+        }
     }
     if (kk == 0 && tid == 0) __hip_atomic_store((fs_gu32*)(p.gstate + face * 16), base / 64u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -114,16 +114,24 @@ int build_denoiser_program(hd_ctx* c) {
     Chain* chp = c->ch;
     const RawTensor *iw = find_raw(c, "denoiser.intro.weight"), *ib = find_raw(c, "denoiser.intro.bias");
     const RawTensor *ew = find_raw(c, "denoiser.ending.weight"), *eb = find_raw(c, "denoiser.ending.bias");
+    // The intro conv: a launch of its own, or -- latent 16, batch <= 64, face-cluster stages available -- the ENTRY of the level-0 encoder stage
+    // (hd_face.hpp: every workgroup computes x of its own and halo image rows from the latents; one launch less per step).  The launch stays as
+    // the first step of that stage's per-GEMM form.
+    std::function<hipError_t(hipStream_t)> intro_run;
     {
         const float *lat = c->ch->lat, *w = c->intro_wT, *b = ib->dev; float* out = c->ch->lv[0].X; float2* sx = c->ch->lv[0].sx;
         unsigned short* xb = c->ch->lv[0].Xb;
         const int M = c->ch->lv[0].M;
-        prog.push_back({"intro", [=](hipStream_t s) -> hipError_t {
-                            if (M >= kLongRunRows) hipLaunchKernelGGL(intro_conv_kernel<16>, dim3((M / 16 + 3) / 4), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
-                            else hipLaunchKernelGGL(intro_conv_kernel<kIntroPx>, dim3((M / kIntroPx + 3) / 4), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
-                            return hipGetLastError();
-                        }});
-        prog.back().out = out; prog.back().out_elems = (size_t)M * 128;
+        intro_run = [=](hipStream_t s) -> hipError_t {
+            if (M >= kLongRunRows) hipLaunchKernelGGL(intro_conv_kernel<16>, dim3((M / 16 + 3) / 4), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
+            else hipLaunchKernelGGL(intro_conv_kernel<kIntroPx>, dim3((M / kIntroPx + 3) / 4), dim3(256), 0, s, lat, w, b, out, xb, sx, B, L, chp->step_state, c->advance);
+            return hipGetLastError();
+        };
+    }
+    const bool fold_intro = c->xcd_ok && c->face_ok && c->intro_fold && B <= 64 && L == 16 && c->ch->lv[0].C == 128 && c->ch->lv[0].H == 16;
+    if (!fold_intro) {
+        prog.push_back({"intro", intro_run});
+        prog.back().out = c->ch->lv[0].X; prog.back().out_elems = (size_t)c->ch->lv[0].M * 128;
     }
     const int enc[4] = {2, 2, 4, 8};
     int bi = 0;
@@ -189,7 +197,7 @@ int build_denoiser_program(hd_ctx* c) {
     };
     // Levels 0 / 1 (latent 16, batch <= 64): a run of blocks as ONE launch with the rows of a face split over a cluster of
     // workgroups (hd_face.hpp); the per-block launches (fused conv1 + chain kernel) stay as the other form of the same op.
-    auto add_face_stage = [&](int nblk, const Level& lv, const GateOut* gate, bool want_xb) {
+    auto add_face_stage = [&](int nblk, const Level& lv, const GateOut* gate, bool want_xb, bool with_intro = false) {
         const int first = bi;
         const bool shape_ok = c->xcd_ok && c->face_ok && B <= 64 && ((lv.C == 128 && lv.H == 16) || (lv.C == 256 && lv.H == 8)) && nblk <= XS_MAXBLK && !(gate && gate->add);
         auto sub = std::make_shared<std::vector<Op>>();
@@ -214,19 +222,25 @@ int build_denoiser_program(hd_ctx* c) {
         if (gate) { fp.outg16 = lv.Xg; fp.gate_c = gate->gate_c; fp.gate_s = gate->gate_s; }
         fp.pool_part = fs.pool_part; fp.flags = fs.sync; fp.gstate = fs.sync + 64 * 16; fp.tmo = c->xcd_tmo_dev; fp.abort_dev = c->abort_dev;
         const bool c128 = lv.C == 128;
+        // the intro conv as this stage's entry (the program then has no intro launch: it is the first step of the per-GEMM form below)
+        const std::function<hipError_t(hipStream_t)> intro_first = with_intro ? intro_run : std::function<hipError_t(hipStream_t)>();
+        if (with_intro) { fp.intro_lat = chp->lat; fp.intro_wT = c->intro_wT; fp.intro_b = ib->dev; fp.intro_step = &chp->step_state->step; }
         Op op;
         op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
-        op.run = [c, chp, fp, sub, c128, first](hipStream_t s) -> hipError_t {
+        op.run = [c, chp, fp, sub, c128, first, intro_first](hipStream_t s) -> hipError_t {
+            // (per-face timesteps and split batches run the per-GEMM form: one FiLM row and every workgroup resident are what the stage needs)
             if (c->xcd_ok && c->face_on && c->chains.size() == 1 && c->film_face_stride == 0) {
                 FStageP r = fp;
                 r.film = c->film_from_cur ? chp->film_cur : c->film_table;
                 r.block_limit = (c->stage_limit_first < 0 || c->stage_limit_first == first) ? c->face_block_limit : 0;
                 r.test_abort = c->stage_test_abort;
+                r.intro_advance = c->advance;
                 const hipError_t e = run_face_stage(c128 ? 128 : 256, c128 ? 32 : c->face_l1_rows, r, s);
                 if (e == hipSuccess) return e;
                 (void)hipGetLastError();                      // (the dynamic-LDS grant was refused: nothing was launched) -> the per-block launches
                 c->face_on = false;
             }
+            if (intro_first) { const hipError_t e = intro_first(s); if (e != hipSuccess) return e; }
             for (auto& o : *sub) { const hipError_t e = o.run(s); if (e != hipSuccess) return e; }
             return hipSuccess;
         };
@@ -235,7 +249,7 @@ int build_denoiser_program(hd_ctx* c) {
     };
     for (int l = 0; l < 4; ++l) {
         if (l >= 2) add_stage(enc[l], c->ch->lv[l], nullptr);
-        else add_face_stage(enc[l], c->ch->lv[l], nullptr, true);
+        else add_face_stage(enc[l], c->ch->lv[l], nullptr, true, l == 0 && fold_intro);
         if (stage_rc) return stage_rc;
         add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
         np = c->ch->lv[l + 1].C / 32; cnt = 32;
@@ -470,6 +484,7 @@ int setup_xcd(hd_ctx* c) {
     c->xcd_ok = true;
     c->xcd2_mask = getenv("HD_XCD2") ? (atoi(getenv("HD_XCD2")) & 3) : 1;
     c->face_ok = getenv("HD_NO_FACE") == nullptr;
+    c->intro_fold = getenv("HD_NO_INTRO_FOLD") == nullptr;
     if (const char* e = getenv("HD_FACE_L1_ROWS")) c->face_l1_rows = atoi(e) == 32 ? 32 : 16;        // per context, like xcd_ok: not a process-wide static (fixtures toggle the variable around make_model)
     return HD_OK;
 }
@@ -1202,6 +1217,7 @@ int hd_get_option(hd_ctx* c, const char* key) {
     if (k == "xcd2") return (c->xcd_ok && c->xcd_on && c->xcd2_on) ? c->xcd2_mask : 0;
     if (k == "xcd_stages") return (int)c->xstages.size();
     if (k == "face_stages") return (int)c->fstages.size();
+    if (k == "intro_fold") return (c->xcd_ok && c->face_ok && c->intro_fold) ? 1 : 0;
     return HD_ERR_INVALID;
 }
 

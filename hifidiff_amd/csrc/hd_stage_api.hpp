@@ -51,7 +51,12 @@ struct FStageP {
     unsigned* tmo;                         // host-visible timeout word (pinned, device-mapped)
     unsigned* abort_dev;                   // the same code in device memory, read at entry by every stage launch (hd_xcd.hpp)
     int test_abort;                        // fault injection: 1000 + b = face 0 gives up its pool wait of block b
-    int block_limit;                       // introspection: stop after this many blocks (<= 0: all)
+    int block_limit;                       // introspection: stop after this many blocks (0: all; < 0: none -- entry and exit only)
+    // level 0, first stage of the encoder: the intro conv (Conv2d(4,128,3,pad 1), models/denoiser/model.py:159-167,235) as the stage's ENTRY --
+    // every workgroup computes x for its own and its halo image rows from the NCHW latents instead of reading X (one launch less per step)
+    const float* intro_lat;                // [B][4][16][16] latents, or NULL: X is read as written by the previous launch
+    const float *intro_wT, *intro_b;       // weights re-laid [36][128] (intro_weight_layout_kernel), bias [128]
+    int* intro_step; int intro_advance;    // the loop's step counter (StepState::step), advanced by the first workgroup when intro_advance
 #ifdef HD_STAMPS
     unsigned long long* stamps;            // [block][workgroup][8]
     int dbg_no_w;                          // timing-only what-if (results are garbage): no weight loads

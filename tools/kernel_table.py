@@ -69,8 +69,9 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 ops = [l.strip() for l in open(sys.argv[2]) if l.strip()]
 n = len(ops)
-intro = [i for i, r in enumerate(rows) if "intro_conv_kernel" in r["Kernel_Name"]]
-starts = [i for i, j in zip(intro, intro[1:]) if j - i == n]
+# a diffusion step ends with the ending conv (the intro conv may be folded into the first stage: no launch of its own to look for)
+ends = [i for i, r in enumerate(rows) if "ending_conv_kernel" in r["Kernel_Name"]]
+starts = [j - n + 1 for i, j in zip(ends, ends[1:]) if j - i == n]
 starts = starts[1:] if len(starts) > 2 else starts
 avg = [sum(dur[s + k] for s in starts) / len(starts) for k in range(n)]
 groups = collections.OrderedDict()

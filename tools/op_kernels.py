@@ -9,9 +9,9 @@ flt = sys.argv[3] if len(sys.argv) > 3 else ""
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# the step graph repeats: find the first index where `len(ops)` consecutive kernels start with the intro conv
+# the step graph repeats: find the first index where `len(ops)` consecutive kernels END with the ending conv, twice in a row
 n = len(ops)
-start = next(i for i in range(len(rows) - 2 * n) if "intro_conv" in names[i] and "intro_conv" in names[i + n])
+start = next(i for i in range(len(rows) - 2 * n) if "ending_conv" in names[i + n - 1] and "ending_conv" in names[i + 2 * n - 1] and (i == 0 or "ending_conv" in names[i - 1]))
 for k in range(n):
     r = rows[start + n + k]                     # second replay: warm
     if flt in ops[k]:

@@ -55,10 +55,9 @@ def main():
         d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     rows = sorted(disp.values(), key=lambda d: d["t0"])
-    intro = [i for i, d in enumerate(rows) if "intro_conv_kernel" in d["name"]]
-    starts = [i for i, j in zip(intro, intro[1:]) if j - i == n_ops]
-    if intro and len(rows) - intro[-1] >= n_ops and (not starts or intro[-1] - starts[-1] == n_ops):
-        starts.append(intro[-1])
+    # a diffusion step ends with the ending conv (the intro conv may be folded into the first stage)
+    ends = [i for i, d in enumerate(rows) if "ending_conv_kernel" in d["name"]]
+    starts = [j - n_ops + 1 for i, j in zip(ends, ends[1:]) if j - i == n_ops]
     if not starts:
         sys.exit("no complete diffusion step found (%d launches per step, %d dispatches)" % (n_ops, len(rows)))
     sel = [rows[s + k] for s in starts for k in range(n_ops)]

@@ -20,10 +20,9 @@ for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])[:18]:
 if len(sys.argv) > 2:
     ops = [l.strip() for l in open(sys.argv[2]) if l.strip()]
     n = len(ops)
-    intro = [i for i, r in enumerate(rows) if "intro_conv_kernel" in r["Kernel_Name"]]
-    starts = [i for i, j in zip(intro, intro[1:]) if j - i == n]
-    if intro and len(rows) - intro[-1] >= n:
-        starts.append(intro[-1])
+    # a diffusion step ends with the ending conv (the intro conv may be folded into the first stage)
+    ends = [i for i, r in enumerate(rows) if "ending_conv_kernel" in r["Kernel_Name"]]
+    starts = [j - n + 1 for i, j in zip(ends, ends[1:]) if j - i == n]
     starts = starts[1:] if len(starts) > 2 else starts           # skip the first (cold) step
     if not starts:
         sys.exit("no full steps found (ops per step %d)" % n)
