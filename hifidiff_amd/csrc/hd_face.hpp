@@ -130,28 +130,34 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
                 const int yy = y0 - 2 + rr, x = xx - 1;
                 patch[i] = (yy >= 0 && yy < S && x >= 0 && x < S) ? p.intro_lat[((size_t)(face * 4 + ci) * S + yy) * S + x] : 0.f;
             }
-            float wl[36][2];
+            f32x2_t wl[36];                                              // (channel lane, channel lane + 64): packed fp32 FMAs, both channels per instruction
 #pragma unroll
-            for (int r = 0; r < 36; ++r) { wl[r][0] = p.intro_wT[r * 128 + lane]; wl[r][1] = p.intro_wT[r * 128 + lane + 64]; }
-            const float b0 = p.intro_b[lane], b1 = p.intro_b[lane + 64];
+            for (int r = 0; r < 36; ++r) wl[r] = (f32x2_t){p.intro_wT[r * 128 + lane], p.intro_wT[r * 128 + lane + 64]};
+            const f32x2_t b01 = {p.intro_b[lane], p.intro_b[lane + 64]};
             __syncthreads();
             const int dy = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? -1 : 2;      // image row y0 + dy; patch row 2 + dy is its centre
             const bool needed = wave < 2 || (wave == 2 ? has_up : has_dn);
             float* dst = wave < 2 ? xt + wave * S * K::XROW : hb + (wave - 2) * S * K::XROW;
             if (needed) {
-#pragma unroll 4
+                // sliding 3 x 3 x 4 window along the image row: 12 new patch values per pixel (LDS broadcast reads), 36 packed FMAs
+                float win[4][3][3];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { win[ci][r][1] = patch[(ci * 6 + 1 + dy + r) * (S + 2)]; win[ci][r][2] = patch[(ci * 6 + 1 + dy + r) * (S + 2) + 1]; }
+#pragma unroll
                 for (int px = 0; px < S; ++px) {
-                    float a0 = b0, a1 = b1;
+                    f32x2_t a = b01;
 #pragma unroll
                     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-                        for (int r = 0; r < 3; ++r)
+                        for (int r = 0; r < 3; ++r) {
+                            win[ci][r][0] = win[ci][r][1]; win[ci][r][1] = win[ci][r][2];
+                            win[ci][r][2] = patch[(ci * 6 + 1 + dy + r) * (S + 2) + px + 2];
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                const float v = patch[(ci * 6 + 1 + dy + r) * (S + 2) + px + k];
-                                a0 = fmaf(v, wl[ci * 9 + r * 3 + k][0], a0);
-                                a1 = fmaf(v, wl[ci * 9 + r * 3 + k][1], a1);
-                            }
+                            for (int k = 0; k < 3; ++k) a = __builtin_elementwise_fma((f32x2_t){win[ci][r][k], win[ci][r][k]}, wl[ci * 9 + r * 3 + k], a);
+                        }
+                    const float a0 = a[0], a1 = a[1];
                     dst[px * K::XROW + lane] = a0; dst[px * K::XROW + lane + 64] = a1;
                 }
             }
