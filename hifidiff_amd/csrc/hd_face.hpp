@@ -13,7 +13,8 @@
 //   B  per-workgroup channel sums of the gate -> the face's pooled mean.
 // Everything else is the chain kernel's arithmetic (hd_chain.hpp): SCA GEMV on the MFMA, G * s, conv3, y, LayerNorm (two-pass,
 // fp32 statistics, bf16 value), conv4, SimpleGate, conv5, x'.  Replaces 2 launches per block (fused conv1, chain kernel).
-// The encoder's first stage also takes the intro conv as its entry (FStageP::intro_lat): own and halo image rows of x straight from the latents.
+// The encoder's first stage also takes the intro conv as its entry (FStageP::intro_lat): own and halo image rows of x straight from the latents;
+// its second stage (level 1) takes the down conv of level 0 the same way (FStageP::down_A: a 32-row x K = 512 GEMM per workgroup).
 //
 // Hand-off (MI355X_MICROARCH.md "Valid forms" row 1, placement-independent): hand-off data is stored write-through (sc1) by
 // every wave, every storing wave drains (s_waitcnt vmcnt(0)), the workgroup's barrier, ONE lane stores the workgroup's flag
@@ -108,10 +109,12 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
     fs_gu32* flags = (fs_gu32*)(p.flags + face * 16);
 
     // ---- entry: own rows of x (written by the previous launch), or -- first stage of the encoder -- the intro conv of own + halo rows ----
-    bool intro = false;
+    bool intro = false;                                              // x (own + halo rows) is computed by this stage's entry: no launch wrote it
     float* hb = reinterpret_cast<float*>(smem + K::T1_OFF);          // x of the halo image rows (above: rows 0..S-1, below: S..2S-1), until block 0's LayerNorm
     if constexpr (C == 128 && OWN == 32) intro = p.intro_lat != nullptr;
-    if (!intro) {
+    bool from_x = !intro;
+    if constexpr (C == 256 && OWN == 16) from_x = p.down_A == nullptr;
+    if (from_x) {
         for (int u = tid; u < OWN * (C / 4); u += K::THREADS) {
             const int r = u / (C / 4), q = u - r * (C / 4);
             *reinterpret_cast<float4*>(xt + r * K::XROW + q * 4) = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + q * 4);
@@ -160,6 +163,56 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
                     const float a0 = a[0], a1 = a[1];
                     dst[px * K::XROW + lane] = a0; dst[px * K::XROW + lane + 64] = a1;
                 }
+            }
+        }
+    }
+    if constexpr (C == 256 && OWN == 16) {
+        if (p.down_A) {
+            // down conv of level 0 (2 x 2, stride 2, 128 -> 256) for the 32 level-1 pixels this workgroup needs: rows 0..15 own (2 image rows of 8),
+            // 16..23 the image row above, 24..31 the one below -- the LayerNorm tile's row order.  A: the 2 x 2 patches gathered from level 0's bf16
+            // copy into LDS ([32][4 taps x 128 channels], over the LayerNorm + gate tiles, which block 0 fills later); one 32-column tile per wave.
+            intro = true;
+            constexpr int DROW = 4 * 128 * 2 + 16;
+            static_assert(32 * DROW <= 64 * K::AROW, "the patch tile fits the LayerNorm + gate tiles");
+            char* sA = smem + K::ALN_OFF;
+            for (int u = tid; u < 32 * 64; u += K::THREADS) {
+                const int r = u >> 6, tap = (u >> 4) & 3, q = u & 15;
+                const int x1 = r & 7;
+                int y1 = kk * K::RI + (r >> 3);
+                bool ok = true;
+                if (r >= 24) { y1 = kk * K::RI + K::RI; ok = has_dn; } else if (r >= 16) { y1 = kk * K::RI - 1; ok = has_up; }
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    const int l0row = face * 256 + (2 * y1 + (tap >> 1)) * 16 + 2 * x1 + (tap & 1);
+                    v = *reinterpret_cast<const uint4*>(p.down_A + (size_t)l0row * 128 + q * 8);
+                }
+                *reinterpret_cast<uint4*>(sA + r * DROW + (tap * 128 + q * 8) * 2) = v;
+            }
+            uint4 wa[16], wb[16];
+            {
+                const uint4* Wl = p.down_W + (size_t)tile * 32 * 64 + lane;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) wa[ks] = xs_ldg_u4(Wl + ks * 64);
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) wb[ks] = xs_ldg_u4(Wl + (16 + ks) * 64);
+            }
+            const float bias = p.down_b[col];
+            __syncthreads();
+            f32x16_t acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const char* ap = sA + (lane & 31) * DROW + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + ks * 32), __builtin_bit_cast(bf16x8_t, wa[ks]), acc, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + (16 + ks) * 32), __builtin_bit_cast(bf16x8_t, wb[ks]), acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                float* dst = r < OWN ? xt + r * K::XROW : hb + (r - OWN) * K::XROW;
+                dst[col] = acc[i] + bias;
             }
         }
     }
@@ -517,7 +570,7 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
         if (!last) publish(base + 2u * (unsigned)blk + 2u);
         HD_FSTAMP(6);
     }
-    if constexpr (C == 128 && OWN == 32) {
+    if constexpr ((C == 128 && OWN == 32) || (C == 256 && OWN == 16)) {
         if (nb_run == 0) {                                           // introspection (block_limit < 0): the entry's x as the stage holds it
             int row0e = row0, tide = tid;                            // opaque: the addresses are formed here, not at the kernel's start (hd_xcd.hpp's exit)
             asm volatile("" : "+s"(row0e), "+v"(tide));

@@ -197,7 +197,7 @@ int build_denoiser_program(hd_ctx* c) {
     };
     // Levels 0 / 1 (latent 16, batch <= 64): a run of blocks as ONE launch with the rows of a face split over a cluster of
     // workgroups (hd_face.hpp); the per-block launches (fused conv1 + chain kernel) stay as the other form of the same op.
-    auto add_face_stage = [&](int nblk, const Level& lv, const GateOut* gate, bool want_xb, bool with_intro = false) {
+    auto add_face_stage = [&](int nblk, const Level& lv, const GateOut* gate, bool want_xb, bool with_intro = false, const Op* down_op = nullptr) {
         const int first = bi;
         const bool shape_ok = c->xcd_ok && c->face_ok && B <= 64 && ((lv.C == 128 && lv.H == 16) || (lv.C == 256 && lv.H == 8)) && nblk <= XS_MAXBLK && !(gate && gate->add);
         auto sub = std::make_shared<std::vector<Op>>();
@@ -223,8 +223,10 @@ int build_denoiser_program(hd_ctx* c) {
         fp.pool_part = fs.pool_part; fp.flags = fs.sync; fp.gstate = fs.sync + 64 * 16; fp.tmo = c->xcd_tmo_dev; fp.abort_dev = c->abort_dev;
         const bool c128 = lv.C == 128;
         // the intro conv as this stage's entry (the program then has no intro launch: it is the first step of the per-GEMM form below)
-        const std::function<hipError_t(hipStream_t)> intro_first = with_intro ? intro_run : std::function<hipError_t(hipStream_t)>();
+        // (level 1: the same for the down conv of level 0)
+        const std::function<hipError_t(hipStream_t)> intro_first = with_intro ? intro_run : down_op ? down_op->run : std::function<hipError_t(hipStream_t)>();
         if (with_intro) { fp.intro_lat = chp->lat; fp.intro_wT = c->intro_wT; fp.intro_b = ib->dev; fp.intro_step = &chp->step_state->step; }
+        if (down_op) { fp.down_A = c->ch->lv[0].Xb; fp.down_W = c->den_down[0].w; fp.down_b = c->den_down[0].bias; }
         Op op;
         op.name = c->den_blocks[first + nblk - 1].name + ".conv5"; op.out = lv.X; op.out_elems = (size_t)lv.M * lv.C; op.out_bf16 = 0;
         op.run = [c, chp, fp, sub, c128, first, intro_first](hipStream_t s) -> hipError_t {
@@ -247,11 +249,14 @@ int build_denoiser_program(hd_ctx* c) {
         prog.push_back(op);
         np = lv.C / 32; cnt = 32;
     };
+    // the down conv of level 0 as the entry of the level-1 stage (same conditions as that stage; HD_NO_DOWN_FOLD=1 keeps the launch)
+    const bool fold_down0 = fold_intro && c->down_fold && c->ch->lv[1].C == 256 && c->ch->lv[1].H == 8 && c->den_down[0].K == 512 && c->den_down[0].N == 256;
+    std::vector<Op> down0;
     for (int l = 0; l < 4; ++l) {
         if (l >= 2) add_stage(enc[l], c->ch->lv[l], nullptr);
-        else add_face_stage(enc[l], c->ch->lv[l], nullptr, true, l == 0 && fold_intro);
+        else add_face_stage(enc[l], c->ch->lv[l], nullptr, true, l == 0 && fold_intro, (l == 1 && fold_down0) ? &down0[0] : nullptr);
         if (stage_rc) return stage_rc;
-        add_down(c, prog, "downs." + std::to_string(l), c->den_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
+        add_down(c, (l == 0 && fold_down0) ? down0 : prog, "downs." + std::to_string(l), c->den_down[l], c->ch->lv[l], c->ch->lv[l + 1]);
         np = c->ch->lv[l + 1].C / 32; cnt = 32;
     }
     // x + idc_conv(id) -> HCA0 (model.py:245-247): the add and the gate are applied by the last mid block's conv5 epilogue.
@@ -485,6 +490,7 @@ int setup_xcd(hd_ctx* c) {
     c->xcd2_mask = getenv("HD_XCD2") ? (atoi(getenv("HD_XCD2")) & 3) : 1;
     c->face_ok = getenv("HD_NO_FACE") == nullptr;
     c->intro_fold = getenv("HD_NO_INTRO_FOLD") == nullptr;
+    c->down_fold = getenv("HD_NO_DOWN_FOLD") == nullptr;
     if (const char* e = getenv("HD_FACE_L1_ROWS")) c->face_l1_rows = atoi(e) == 32 ? 32 : 16;        // per context, like xcd_ok: not a process-wide static (fixtures toggle the variable around make_model)
     return HD_OK;
 }
@@ -1218,6 +1224,7 @@ int hd_get_option(hd_ctx* c, const char* key) {
     if (k == "xcd_stages") return (int)c->xstages.size();
     if (k == "face_stages") return (int)c->fstages.size();
     if (k == "intro_fold") return (c->xcd_ok && c->face_ok && c->intro_fold) ? 1 : 0;
+    if (k == "down_fold") return (c->xcd_ok && c->face_ok && c->intro_fold && c->down_fold) ? 1 : 0;
     return HD_ERR_INVALID;
 }
 

@@ -57,6 +57,10 @@ struct FStageP {
     const float* intro_lat;                // [B][4][16][16] latents, or NULL: X is read as written by the previous launch
     const float *intro_wT, *intro_b;       // weights re-laid [36][128] (intro_weight_layout_kernel), bias [128]
     int* intro_step; int intro_advance;    // the loop's step counter (StepState::step), advanced by the first workgroup when intro_advance
+    // level 1, first stage of the encoder: the down conv of level 0 (Conv2d(128,256,2,2), models/denoiser/model.py:236-241) as the stage's ENTRY --
+    // every workgroup gathers the 2 x 2 patches of its own and its halo image rows from level 0's bf16 copy and runs the K = 512 GEMM itself
+    const unsigned short* down_A;          // level 0's Xb [B * 256][128] bf16, or NULL: X is read as written by the previous launch
+    const uint4* down_W; const float* down_b;            // packed B fragments [8 tiles][32 k-steps][64] (k = tap * 128 + c), bias [256]
 #ifdef HD_STAMPS
     unsigned long long* stamps;            // [block][workgroup][8]
     int dbg_no_w;                          // timing-only what-if (results are garbage): no weight loads
