@@ -14,7 +14,8 @@
 // Everything else is the chain kernel's arithmetic (hd_chain.hpp): SCA GEMV on the MFMA, G * s, conv3, y, LayerNorm (two-pass,
 // fp32 statistics, bf16 value), conv4, SimpleGate, conv5, x'.  Replaces 2 launches per block (fused conv1, chain kernel).
 // The encoder's first stage also takes the intro conv as its entry (FStageP::intro_lat): own and halo image rows of x straight from the latents;
-// its second stage (level 1) takes the down conv of level 0 the same way (FStageP::down_A: a 32-row x K = 512 GEMM per workgroup).
+// its second stage (level 1) takes the down conv of level 0 the same way (FStageP::down_A: a 32-row x K = 512 GEMM per workgroup), and the
+// level-0 decoder stage the last up conv (FStageP::up_A: 24 level-1 pixels x K = 256 x 512 sub-pixel-major columns, added to the skip X holds).
 //
 // Hand-off (MI355X_MICROARCH.md "Valid forms" row 1, placement-independent): hand-off data is stored write-through (sc1) by
 // every wave, every storing wave drains (s_waitcnt vmcnt(0)), the workgroup's barrier, ONE lane stores the workgroup's flag
@@ -164,6 +165,76 @@ __global__ __launch_bounds__((FaceCfg<C, OWN>::THREADS), 2) void naf_face_stage_
                     dst[px * K::XROW + lane] = a0; dst[px * K::XROW + lane + 64] = a1;
                 }
             }
+        }
+    }
+    if constexpr (C == 128 && OWN == 32) {
+        if (p.up_A) {
+            // rows of the A tile: 0..7 the level-1 image row under the own rows (y1 = kk), 8..15 the one above, 16..23 the one below, 24..31 zero.
+            // Wave w = sub-pixel (dy, dx) = (w >> 1, w & 1): its four 32-column tiles are the 128 channels of that sub-pixel; the output of level-1
+            // pixel (y1, x1) lands at level-0 pixel (2 y1 + dy, 2 x1 + dx).  Of the halo rows only the adjacent image row is kept (above: dy = 1, below: dy = 0).
+            constexpr int UROW = 256 * 2 + 16;
+            static_assert(32 * UROW <= 64 * K::AROW, "the up conv's A tile fits the LayerNorm + gate tiles");
+            char* sA = smem + K::ALN_OFF;
+            for (int u = tid; u < 32 * 32; u += K::THREADS) {
+                const int r = u >> 5, q = u & 31, x1 = r & 7, grp = r >> 3;
+                const int y1 = grp == 0 ? kk : grp == 1 ? kk - 1 : kk + 1;
+                const bool ok = grp == 0 || (grp == 1 && has_up) || (grp == 2 && has_dn);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) v = *reinterpret_cast<const uint4*>(p.up_A + (size_t)(face * 64 + y1 * 8 + x1) * 256 + q * 8);
+                *reinterpret_cast<uint4*>(sA + r * UROW + q * 16) = v;
+            }
+            // weights in half tiles of 8 k-steps, three register sets: two halves (16 KB per wave) are in flight ahead of the MFMAs -- with one
+            // ahead the entry was a chain of eight L2 round trips (5.7 us)
+            uint4 wq[3][8];
+            const uint4* Wl = p.up_W + (size_t)(wave * 4) * 16 * 64 + lane;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) wq[h][ks] = xs_ldg_u4(Wl + (h * 8 + ks) * 64);
+            __syncthreads();                                         // the A tile is staged, and the skip rows are in xt
+            const char* ap = sA + (lane & 31) * UROW + (lane >> 5) * 16;
+            const int dyw = wave >> 1, dxw = wave & 1;
+            f32x16_t acc;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {                           // chunk ch = half (ch & 1) of tile ch >> 1
+                if (ch + 2 < 8) {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) wq[(ch + 2) % 3][ks] = xs_ldg_u4(Wl + ((ch + 2) * 8 + ks) * 64);
+                }
+                if ((ch & 1) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + ((ch & 1) * 8 + ks) * 32),
+                                                                  __builtin_bit_cast(bf16x8_t, wq[ch % 3][ks]), acc, 0, 0, 0);
+                if (ch & 1) {
+                    const int c = (ch >> 1) * 32 + (lane & 31);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), grp = r >> 3, px = 2 * (r & 7) + dxw;
+                        if (grp == 0) xt[(dyw * K::S + px) * K::XROW + c] += acc[i];
+                        else if (grp == 1 && dyw == 1) hb[px * K::XROW + c] = acc[i];
+                        else if (grp == 2 && dyw == 0) hb[(K::S + px) * K::XROW + c] = acc[i];
+                    }
+                }
+            }
+            // the halo rows' skip (X holds the encoder's output) joins their up term in hb: block 0 then takes its halo from LDS, as with the intro entry
+            __syncthreads();
+            for (int u = tid; u < 2 * K::S * (C / 4); u += K::THREADS) {
+                const int r = u / (C / 4), q = u - r * (C / 4);
+                const bool up = r < K::S;
+                if (up ? has_up : has_dn) {
+                    const int grow = up ? row0 - K::S + r : row0 + OWN + (r - K::S);
+                    const float4 v = *reinterpret_cast<const float4*>(p.X + (size_t)grow * C + q * 4);
+                    float4* d = reinterpret_cast<float4*>(hb + r * K::XROW + q * 4);
+                    float4 t = *d;
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                    *d = t;
+                }
+            }
+            intro = true;
         }
     }
     if constexpr (C == 256 && OWN == 16) {

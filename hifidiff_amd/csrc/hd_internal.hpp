@@ -233,6 +233,7 @@ struct hd_ctx {
     bool face_ok = false;                     // decided per context in setup_xcd (HD_NO_FACE / HD_NO_XCD at the time the context is finalized)
     bool face_on = true;                      // run-time switch (hd_set_option "face")
     int face_block_limit = 0;
+    bool up_fold = true;                      // the last up conv as the entry of the level-0 decoder stage (HD_NO_UP_FOLD=1: its own launch)
     bool down_fold = true;                    // the down conv of level 0 as the entry of the level-1 encoder stage (HD_NO_DOWN_FOLD=1: its own launch)
     bool intro_fold = true;                   // the intro conv as the entry of the level-0 encoder stage (HD_NO_INTRO_FOLD=1 at context creation: its own launch)
     int face_l1_rows = 16;                    // pixel rows per workgroup of the level-1 stage: 16 = 256 workgroups (every CU), 32 = 128 (HD_FACE_L1_ROWS, experiments)

@@ -197,7 +197,8 @@ int build_denoiser_program(hd_ctx* c) {
     };
     // Levels 0 / 1 (latent 16, batch <= 64): a run of blocks as ONE launch with the rows of a face split over a cluster of
     // workgroups (hd_face.hpp); the per-block launches (fused conv1 + chain kernel) stay as the other form of the same op.
-    auto add_face_stage = [&](int nblk, const Level& lv, const GateOut* gate, bool want_xb, bool with_intro = false, const Op* down_op = nullptr) {
+    auto add_face_stage = [&](int nblk, const Level& lv, const GateOut* gate, bool want_xb, bool with_intro = false, const Op* down_op = nullptr,
+                              const Op* up_op = nullptr, const unsigned short* up_A = nullptr) {
         const int first = bi;
         const bool shape_ok = c->xcd_ok && c->face_ok && B <= 64 && ((lv.C == 128 && lv.H == 16) || (lv.C == 256 && lv.H == 8)) && nblk <= XS_MAXBLK && !(gate && gate->add);
         auto sub = std::make_shared<std::vector<Op>>();
@@ -224,7 +225,8 @@ int build_denoiser_program(hd_ctx* c) {
         const bool c128 = lv.C == 128;
         // the intro conv as this stage's entry (the program then has no intro launch: it is the first step of the per-GEMM form below)
         // (level 1: the same for the down conv of level 0)
-        const std::function<hipError_t(hipStream_t)> intro_first = with_intro ? intro_run : down_op ? down_op->run : std::function<hipError_t(hipStream_t)>();
+        const std::function<hipError_t(hipStream_t)> intro_first = with_intro ? intro_run : down_op ? down_op->run : up_op ? up_op->run : std::function<hipError_t(hipStream_t)>();
+        if (up_op) { fp.up_A = up_A; fp.up_W = c->den_up[3].w; }        // level 0's decoder stage: the last up conv (X holds the encoder skip)
         if (with_intro) { fp.intro_lat = chp->lat; fp.intro_wT = c->intro_wT; fp.intro_b = ib->dev; fp.intro_step = &chp->step_state->step; }
         if (down_op) { fp.down_A = c->ch->lv[0].Xb; fp.down_W = c->den_down[0].w; fp.down_b = c->den_down[0].bias; }
         Op op;
@@ -272,14 +274,18 @@ int build_denoiser_program(hd_ctx* c) {
         const Level &hi = c->ch->lv[l + 1], &lo = c->ch->lv[l];
         // x = PixelShuffle(up(x)) + enc_skip (model.py:249-251); the epilogue also leaves the bf16 copy and the
         // LayerNorm partials of the new rows (one per 32 channels)
-        add_up(c, prog, "ups." + std::to_string(i), c->den_up[i], cond ? hi.Yb : hi.Xb, true, hi.M, hi.H, hi.C, lo.X, lo.X, 2, lo.Xb, lo.sx);
+        // the last up conv as the entry of the level-0 decoder stage (same conditions as that stage; HD_NO_UP_FOLD=1 keeps the launch)
+        const bool fold_up = i == 3 && fold_intro && c->up_fold && lo.C == 128 && lo.H == 16 && c->den_up[3].K == 256 && c->den_up[3].N == 512;
+        std::vector<Op> up3;
+        add_up(c, fold_up ? up3 : prog, "ups." + std::to_string(i), c->den_up[i], cond ? hi.Yb : hi.Xb, true, hi.M, hi.H, hi.C, lo.X, lo.X, 2, lo.Xb, lo.sx);
         np = lo.C / 32; cnt = 32;
         GateOut g; g.gate_c = c->ch->gate_c[i + 1]; g.gate_s = c->ch->gate_s[i + 1];
         if (l >= 2) {
             add_stage(2, lo, cond ? &g : nullptr);
             if (stage_rc) return stage_rc;
         } else {
-            add_face_stage(2, lo, cond ? &g : nullptr, !cond);          // unconditional: the up conv / ending read the blocks' own output
+            // unconditional: the up conv / ending read the blocks' own output
+            add_face_stage(2, lo, cond ? &g : nullptr, !cond, false, nullptr, fold_up ? &up3[0] : nullptr, cond ? hi.Yb : hi.Xb);
             if (stage_rc) return stage_rc;
         }
         if (cond) add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
@@ -491,6 +497,7 @@ int setup_xcd(hd_ctx* c) {
     c->face_ok = getenv("HD_NO_FACE") == nullptr;
     c->intro_fold = getenv("HD_NO_INTRO_FOLD") == nullptr;
     c->down_fold = getenv("HD_NO_DOWN_FOLD") == nullptr;
+    c->up_fold = getenv("HD_NO_UP_FOLD") == nullptr;
     if (const char* e = getenv("HD_FACE_L1_ROWS")) c->face_l1_rows = atoi(e) == 32 ? 32 : 16;        // per context, like xcd_ok: not a process-wide static (fixtures toggle the variable around make_model)
     return HD_OK;
 }
@@ -1224,6 +1231,7 @@ int hd_get_option(hd_ctx* c, const char* key) {
     if (k == "xcd_stages") return (int)c->xstages.size();
     if (k == "face_stages") return (int)c->fstages.size();
     if (k == "intro_fold") return (c->xcd_ok && c->face_ok && c->intro_fold) ? 1 : 0;
+    if (k == "up_fold") return (c->xcd_ok && c->face_ok && c->intro_fold && c->up_fold) ? 1 : 0;
     if (k == "down_fold") return (c->xcd_ok && c->face_ok && c->intro_fold && c->down_fold) ? 1 : 0;
     return HD_ERR_INVALID;
 }

@@ -61,6 +61,10 @@ struct FStageP {
     // every workgroup gathers the 2 x 2 patches of its own and its halo image rows from level 0's bf16 copy and runs the K = 512 GEMM itself
     const unsigned short* down_A;          // level 0's Xb [B * 256][128] bf16, or NULL: X is read as written by the previous launch
     const uint4* down_W; const float* down_b;            // packed B fragments [8 tiles][32 k-steps][64] (k = tap * 128 + c), bias [256]
+    // level 0, decoder stage: the last up conv (1x1 conv 256 -> 512 + PixelShuffle(2) + encoder skip, models/denoiser/model.py:249-251) as the stage's
+    // ENTRY -- X holds the skip; every workgroup adds the up conv of the 24 level-1 pixels under its own and halo image rows (one 32-row MFMA tile)
+    const unsigned short* up_A;            // level 1's bf16 rows [B * 64][256] (HCA output, or the blocks' own copy), or NULL: X already holds the sum
+    const uint4* up_W;                     // packed B fragments [16 tiles][16 k-steps][64], output channel n' = sub-pixel * 128 + c (no bias)
 #ifdef HD_STAMPS
     unsigned long long* stamps;            // [block][workgroup][8]
     int dbg_no_w;                          // timing-only what-if (results are garbage): no weight loads

@@ -215,7 +215,7 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
 
 
 def stage_forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e-3):
-    """The persistent stages of the DEFAULT program (61 launches at latent 16, batch <= 64: hd_face.hpp levels 0 / 1, hd_xcd.hpp /
+    """The persistent stages of the DEFAULT program (60 launches at latent 16, batch <= 64: hd_face.hpp levels 0 / 1, hd_xcd.hpp /
     hd_xcd2.hpp levels 2 / 3), block by block: the stage is stopped after b blocks (`face_block_limit` / `xcd_phase_limit`
     = 5 b), the residual stream it has reached is read back, the oracle's arithmetic for block b + 1 alone
     (conditional_naf.py:108-136, bf16-operand emulation) is applied to exactly those values and compared with what the stage
@@ -273,15 +273,21 @@ def stage_forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bo
             # oracle's arithmetic for that conv on ITS inputs
             producer = ("intro" if l == 0 else f"downs.{l - 1}") if parts[1] == "encoders" else f"ups.{parts[2]}"
             if (names[i - 1] if i > 0 else "") != producer:
-                if producer != "intro":
+                if producer.startswith("downs"):
                     run_to(i)
                     src0 = _nchw(_read(L, ctx, "X" + str(l - 1)), B, C // 2, 2 * H)
+                elif producer.startswith("ups"):                      # X holds the encoder's skip, the level above its (HCA) output
+                    run_to(i)
+                    src0 = _nchw(_read(L, ctx, ("Y" if model.engine.conditional else "X") + str(l + 1)), B, 2 * C, H // 2)
+                    skip0 = _nchw(_read(L, ctx, "X" + sl), B, C, H)
                 run_to(i + 1, face_limit=-1, first=first)
                 cur = _nchw(_read(L, ctx, "X" + sl), B, C, H)
                 if producer == "intro":
                     want0 = F.conv2d(x, P["denoiser.intro.weight"], P["denoiser.intro.bias"], padding=1)
-                else:
+                elif producer.startswith("downs"):
                     want0 = O._gemm_conv(src0, P[f"denoiser.{producer}.weight"], P[f"denoiser.{producer}.bias"], PR, stride=2)
+                else:
+                    want0 = O._up_shuffle(src0, P[f"denoiser.{producer}.0.weight"], 2, PR) + skip0
                 check(i, producer + " (stage entry)", "X", _read(L, ctx, "X" + sl)[:M * C], _rows(want0), False)
             else:
                 run_to(i)
