@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhifidiff_hip.so")
 # translation units (compiled in parallel, one hipcc each) and the headers they include
 UNITS = [os.path.join(_HERE, "csrc", f) for f in ("hd_lib.hip", "hd_aux.hip", "hd_stages.hip", "hd_strip.hip", "hd_dispatch_ln.hip", "hd_dispatch_lnface.hip", "hd_dispatch_bf16.hip", "hd_dispatch_misc.hip")]
-SOURCES = UNITS + [os.path.join(_HERE, "csrc", f) for f in ("hd_gemm.hpp", "hd_dispatch.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_vae.hpp", "hd_internal.hpp", "hd_stage_api.hpp", "hd_xcd.hpp", "hd_xcd2.hpp", "hd_face.hpp", "hd_strip.hpp", "hd_wide.hpp")]
+SOURCES = UNITS + [os.path.join(_HERE, "csrc", f) for f in ("hd_gemm.hpp", "hd_dispatch.hpp", "hd_kernels.hpp", "hd_chain.hpp", "hd_conv.hpp", "hd_cr.hpp", "hd_vae.hpp", "hd_internal.hpp", "hd_stage_api.hpp", "hd_xcd.hpp", "hd_xcd2.hpp", "hd_face.hpp", "hd_strip.hpp", "hd_wide.hpp", "hd_end.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hifidiff_hip.h")
 
 

@@ -25,6 +25,7 @@
 #include "hd_dispatch.hpp"
 #include "hd_gemm.hpp"
 #include "hd_kernels.hpp"
+#include "hd_end.hpp"
 #include "hd_vae.hpp"
 #include "hd_stage_api.hpp"
 
@@ -233,6 +234,8 @@ struct hd_ctx {
     bool face_ok = false;                     // decided per context in setup_xcd (HD_NO_FACE / HD_NO_XCD at the time the context is finalized)
     bool face_on = true;                      // run-time switch (hd_set_option "face")
     int face_block_limit = 0;
+    bool end_fold = getenv("HD_NO_END_FOLD") == nullptr;   // the last HCA conv + the ending conv as one launch (hd_end.hpp); end_fused: cleared when its launch is refused
+    bool end_fused = true;
     bool up_fold = true;                      // the last up conv as the entry of the level-0 decoder stage (HD_NO_UP_FOLD=1: its own launch)
     bool down_fold = true;                    // the down conv of level 0 as the entry of the level-1 encoder stage (HD_NO_DOWN_FOLD=1: its own launch)
     bool intro_fold = true;                   // the intro conv as the entry of the level-0 encoder stage (HD_NO_INTRO_FOLD=1 at context creation: its own launch)

@@ -269,6 +269,9 @@ int build_denoiser_program(hd_ctx* c) {
         add_naf_block(c, prog, c->den_blocks[bi++], c->ch->lv[4], nullptr, &np, &cnt, (cond && j == 7) ? &g0 : nullptr);
     }
     if (cond) add_hca(c, prog, "hcas.0", c->hca[0], c->ch->lv[4].Xg, c->ch->lv[4].Y, c->ch->lv[4].Yb, c->ch->lv[4].M, c->ch->lv[4].H);
+    // (with the other folds: the program of the persistent stages; the one-launch-per-GEMM programs keep every launch and its tap)
+    const bool fuse_end = cond && fold_intro && c->end_fold && L == 16 && c->ch->lv[0].C == 128 && c->ch->lv[0].H == 16 && !c->hca[4].centre_only;
+    std::vector<Op> hca4;
     for (int i = 0; i < 4; ++i) {
         const int l = 3 - i;
         const Level &hi = c->ch->lv[l + 1], &lo = c->ch->lv[l];
@@ -288,16 +291,38 @@ int build_denoiser_program(hd_ctx* c) {
             add_face_stage(2, lo, cond ? &g : nullptr, !cond, false, nullptr, fold_up ? &up3[0] : nullptr, cond ? hi.Yb : hi.Xb);
             if (stage_rc) return stage_rc;
         }
-        if (cond) add_hca(c, prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
+        // the last HCA conv and the ending conv as ONE launch (hd_end.hpp; latent 16, conditional refiner; HD_NO_END_FOLD=1 keeps the two launches):
+        // the HCA op is then the first step of the ending op's two-launch form
+        if (cond) add_hca(c, (i == 3 && fuse_end) ? hca4 : prog, "hcas." + std::to_string(i + 1), c->hca[i + 1], lo.Xg, lo.Y, i < 3 ? lo.Yb : nullptr, lo.M, lo.H);
     }
     {
         const float *X = cond ? c->ch->lv[0].Y : c->ch->lv[0].X, *w = c->ending_wT, *b = eb->dev; float* eps = c->ch->eps;
         const int M = c->ch->lv[0].M;
         Chain* chp = c->ch;
+        EndP ep{};
+        std::function<hipError_t(hipStream_t)> hca4_run;
+        if (fuse_end) {
+            ep.B = B; ep.Xg = c->ch->lv[0].Xg; ep.W = c->hca[4].fused.w; ep.bias = c->hca[4].fused.bias; ep.ewT = w; ep.eb = b; ep.eps = eps;
+            hca4_run = hca4[0].run;
+        }
         prog.push_back({"ending", [=](hipStream_t s) -> hipError_t {
                             // sampling loop (film_from_cur): the launch also applies the scheduler update to this
                             // chain's latents and stages the next step's FiLM row
                             SchedArgs sa{};
+                            if (fuse_end && c->end_fused) {
+                                EndP q = ep;
+                                if (c->film_from_cur) {
+                                    const size_t per_face = (size_t)4 * L * L;
+                                    q.sa.lat = chp->lat; q.sa.coef = c->coef_dev; q.sa.st = chp->step_state;
+                                    q.sa.elem0 = (int)(chp->face0 * per_face); q.sa.n_total = (int)(c->B * per_face);
+                                    q.sa.film_table = c->film_table; q.sa.film_cur = chp->film_cur; q.sa.film_total = c->film_total;
+                                }
+                                const hipError_t e = launch_hca_ending(q, s);
+                                if (e == hipSuccess) return e;
+                                (void)hipGetLastError();              // the dynamic-LDS grant was refused: nothing was launched -> the two launches
+                                c->end_fused = false;
+                            }
+                            if (hca4_run) { const hipError_t e = hca4_run(s); if (e != hipSuccess) return e; }
                             const bool long_runs = M >= kLongRunRows;
                             unsigned nb = (unsigned)((M / (long_runs ? 16 : kEndingPx) + 3) / 4);
                             if (c->film_from_cur) {
@@ -1231,6 +1256,7 @@ int hd_get_option(hd_ctx* c, const char* key) {
     if (k == "xcd_stages") return (int)c->xstages.size();
     if (k == "face_stages") return (int)c->fstages.size();
     if (k == "intro_fold") return (c->xcd_ok && c->face_ok && c->intro_fold) ? 1 : 0;
+    if (k == "end_fold") return (c->end_fold && c->end_fused) ? 1 : 0;
     if (k == "up_fold") return (c->xcd_ok && c->face_ok && c->intro_fold && c->up_fold) ? 1 : 0;
     if (k == "down_fold") return (c->xcd_ok && c->face_ok && c->intro_fold && c->down_fold) ? 1 : 0;
     return HD_ERR_INVALID;

@@ -227,7 +227,7 @@ def test_every_launch_is_reproducible(gpu, weights16, model2_launches):
     import determinism_scan
     m = make_model(weights16)
     n, bad = determinism_scan.scan(64, 16, 3, model=m, verbose=False, per_face=False)   # one timestep for all faces: the sampling loop's kernels
-    assert n == 60 and not bad, (n, bad)                                               # levels 0-3 as eight persistent stages; the intro conv, the first down conv and the last up conv are stage entries
+    assert n == 59 and not bad, (n, bad)                                               # levels 0-3 as eight persistent stages; the intro conv, the first down conv and the last up conv are stage entries; the last HCA conv + the ending conv are one launch
     n, bad = determinism_scan.scan(64, 16, 3, model=model2_launches, verbose=False, per_face=False)   # ... and as one launch per GEMM
     assert n == 151 and not bad, (n, bad)
     n, bad = determinism_scan.scan(64, 16, 3, model=model2_launches, verbose=False, per_face=True)    # a timestep per face: the LdF32LNFace kernels
@@ -668,7 +668,7 @@ def test_xcd_stages_match_the_per_gemm_launches_bit_for_bit(gpu, weights16):
         _opt(m, "xcd", 1)
         e1 = m(x, 500, crf, crl).sample.clone()
         assert L.hd_get_option(m.engine.ctx, b"xcd") == 1 and L.hd_get_option(m.engine.ctx, b"xcd_stages") == 8    # block tables of the 4 + 4 stages
-        assert L.hd_num_ops(m.engine.ctx, 0) == 60                     # 151 launches with one per GEMM: 80 became 4 (levels 2 / 3), 16 + the intro conv + the first down conv + the last up conv became 4 (levels 0 / 1)
+        assert L.hd_num_ops(m.engine.ctx, 0) == 59                     # 151 launches with one per GEMM: 80 became 4 (levels 2 / 3), 16 + the intro conv + the first down conv + the last up conv became 4 (levels 0 / 1), hcas.4 + ending became 1
         assert torch.equal(m(x, 500, crf, crl).sample, e1)              # reproducible
         _opt(m, "xcd_force_global", 1)
         eg = m(x, 500, crf, crl).sample.clone()
@@ -805,7 +805,7 @@ def test_teacher_forced_op_parity(gpu, weights16, model2_launches):
 
 
 def test_persistent_stages_block_by_block_against_oracle(gpu, weights16):
-    """The eight persistent stages of the program the benchmark times (60 launches: hd_face.hpp levels 0 / 1, hd_xcd.hpp levels
+    """The eight persistent stages of the program the benchmark times (59 launches: hd_face.hpp levels 0 / 1, hd_xcd.hpp levels
     2 / 3), each stopped after b blocks (`face_block_limit` / `xcd_phase_limit`): the oracle's arithmetic for ONE
     ConditionalNAFBlock (conditional_naf.py:108-136, bf16-operand emulation) applied to the residual stream the stage itself had
     reached before the block, against what the stage holds after it (x' itself as an fp32 output, and the block's own
@@ -819,7 +819,7 @@ def test_persistent_stages_block_by_block_against_oracle(gpu, weights16):
         x, crl, crf = synth.sample_inputs(B, 16)
         rep = []
         worst = op_forced.stage_forced_scan(m, weights16, x, crl, crf, 500.0, rep)
-        assert worst["stages"] == 8 and len(rep) == 59, (worst, len(rep))      # 24 blocks x 2 + 8 exit copies + the three folded producers (intro, downs.0, ups.3) at their stages' entries
+        assert worst["stages"] == 8 and len(rep) == 60, (worst, len(rep))      # 24 blocks x 2 + 8 exit copies + the three folded producers (intro, downs.0, ups.3) at their stages' entries + the fused hcas.4 / ending launch
         assert not [r for r in rep if "<<<<<<" in r], [r for r in rep if "<<<<<<" in r][:8]
         assert worst["fp32"] <= 3e-4 and worst["bf16"] <= 3e-3, (B, worst)
 
@@ -961,9 +961,9 @@ def test_face_cluster_stages_of_the_shallow_levels(gpu, weights16):
         xd, cld, cfd = x.cuda(), crl.cuda(), crf.cuda()
         _opt(m, "face", 1)
         e1 = m(xd, 500, cfd, cld).sample.clone()
-        assert L.hd_get_option(m.engine.ctx, b"face_stages") == 4 and L.hd_num_ops(m.engine.ctx, 0) == 60 and L.hd_get_option(m.engine.ctx, b"intro_fold") == 1 and L.hd_get_option(m.engine.ctx, b"down_fold") == 1 and L.hd_get_option(m.engine.ctx, b"up_fold") == 1
+        assert L.hd_get_option(m.engine.ctx, b"face_stages") == 4 and L.hd_num_ops(m.engine.ctx, 0) == 59 and L.hd_get_option(m.engine.ctx, b"end_fold") == 1 and L.hd_get_option(m.engine.ctx, b"intro_fold") == 1 and L.hd_get_option(m.engine.ctx, b"down_fold") == 1 and L.hd_get_option(m.engine.ctx, b"up_fold") == 1
         assert torch.equal(m(xd, 500, cfd, cld).sample, e1)
-        names = [L.hd_debug_op_name(m.engine.ctx, 0, i).decode() for i in range(60)]
+        names = [L.hd_debug_op_name(m.engine.ctx, 0, i).decode() for i in range(59)]
         L.hd_debug_limit_ops(m.engine.ctx, 0, names.index("denoiser.encoders.0.1.conv5") + 1)
         m(xd, 500, cfd, cld)
         xa = _read_dbg(m, "X0", B * 256 * 128)
@@ -1135,7 +1135,7 @@ def test_the_cost_of_leaving_the_benchmark_shapes_is_bounded(gpu, weights16):
     steps (2.08 ms) at any batch from 65 to 128, which is more than the launches take at either end of that range."""
     import batch_sweep
     rows = {r[0]: r for r in batch_sweep.sweep(16, (64, 65, 128), weights=weights16, n_steps=16, reps=2)}
-    assert (rows[64][1], rows[65][1], rows[128][1]) == (60, 151, 151), rows
+    assert (rows[64][1], rows[65][1], rows[128][1]) == (59, 151, 151), rows
     per_face = {b: rows[b][3] for b in rows}
     assert per_face[65] <= 1.7 * per_face[64], per_face
     assert per_face[128] <= 1.0 * per_face[64], per_face           # measured 0.84x: the per-GEMM launches barely notice the row count

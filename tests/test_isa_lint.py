@@ -31,7 +31,7 @@ def _p(r):
     return r["pretty"].replace("void ", "").replace("hd::", "")
 
 
-# the stage instantiations the benchmark's 60-launch step runs (latent 16, batch <= 64): level 0 / 1 face clusters, level 2 in the
+# the stage instantiations the benchmark's 59-launch step runs (latent 16, batch <= 64): level 0 / 1 face clusters, level 2 in the
 # autonomous-wave form, level 3 in the K-split form.  The other instantiations (xcd_stage<512,16>: 3 spilled registers,
 # naf_face_stage<256,32>: 30, xcd2<1024,4>) are the forms hd_set_option / HD_XCD2 / HD_FACE_L1_ROWS select for A/B runs.
 BENCH_STAGES = ("xcd_stage_kernel<1024, 4>", "xcd2_stage_kernel<512, 16>", "naf_face_stage_kernel<128, 32>", "naf_face_stage_kernel<256, 16>")

@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "batch_sweep.txt"))
     a = ap.parse_args()
     lines = ["tools/batch_sweep.py (MI355X): ms per diffusion step (HIP events around the graph replay loop, best of 3 short loops) and launches per step.",
-             "Latent 16: the persistent stages (60 launches) take batches <= 64; above that every level runs one launch per GEMM (151 launches), whose",
+             "Latent 16: the persistent stages (59 launches) take batches <= 64; above that every level runs one launch per GEMM (151 launches), whose",
              "kernel times barely depend on the row count at these sizes -- the step gets longer, the face cheaper.  Latent 32: one launch per GEMM at",
              "every batch; the many-row GEMM forms (hd_wide.hpp, gemm_deep) are selected by row count (batch 64: 1024 / 4096 rows at levels 3 / 2).", ""]
     for latent, batches in ((16, (32, 64, 65, 128)), (32, (32, 64, 128))):

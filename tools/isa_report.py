@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "hifidiff_amd", "csrc", "build")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
-# kernels of the benchmark's 60-launch step that must hold no scratch access
+# kernels of the benchmark's 59-launch step that must hold no scratch access
 HOT_PREFIXES = ("xcd_stage_kernel", "xcd2_stage_kernel", "naf_face_stage_kernel", "naf_chain_kernel", "naf_strip_dwgate_kernel")
 BAD_OPSEL = re.compile(r"op_sel:\[0,1,0\]\s+op_sel_hi:\[1,1,0\]")
 

@@ -215,7 +215,7 @@ def forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e
 
 
 def stage_forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bound=3e-3):
-    """The persistent stages of the DEFAULT program (60 launches at latent 16, batch <= 64: hd_face.hpp levels 0 / 1, hd_xcd.hpp /
+    """The persistent stages of the DEFAULT program (59 launches at latent 16, batch <= 64: hd_face.hpp levels 0 / 1, hd_xcd.hpp /
     hd_xcd2.hpp levels 2 / 3), block by block: the stage is stopped after b blocks (`face_block_limit` / `xcd_phase_limit`
     = 5 b), the residual stream it has reached is read back, the oracle's arithmetic for block b + 1 alone
     (conditional_naf.py:108-136, bf16-operand emulation) is applied to exactly those values and compared with what the stage
@@ -311,6 +311,15 @@ def stage_forced_scan(model, P, x, crl, crf, t, report, fp32_bound=3e-4, bf16_bo
                 check(i, name, "Xg", _read(L, ctx, "Xg" + sl)[:M * C], _rows(PR.q(cur * (1.0 + wc + ws))), True)
             else:
                 check(i, name, "Xb", _read(L, ctx, "Xb" + sl)[:M * C], _rows(PR.q(cur)), True)
+        # the step's last launch when it is the last HCA conv + the ending conv in one (hd_end.hpp): on ITS input, the gated decoder output
+        if names[-1] == "ending" and model.engine.conditional and (n < 2 or names[-2] != "hcas.4"):
+            run_to(n - 1)
+            xg = _nchw(_read(L, ctx, "Xg0"), B, 128, latent)
+            run_to(n)
+            q = "denoiser.hcas.4"
+            y0 = torch.relu(O._conv_bn(xg, P, q + ".fused_mlp.0", q + ".fused_mlp.1", PR, padding=1))
+            want = F.conv2d(y0, P["denoiser.ending.weight"], P["denoiser.ending.bias"], padding=1)
+            check(n - 1, "hcas.4 + ending (one launch)", "eps", _read(L, ctx, "eps")[:want.numel()], want.reshape(-1), False)
     finally:
         L.hd_set_option(ctx, b"stage_limit_first", -1)
         L.hd_set_option(ctx, b"face_block_limit", 0)

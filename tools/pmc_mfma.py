@@ -36,6 +36,8 @@ def family(k):
         return f"naf_strip_dwgate<{m.group(1)},{m.group(2)}> (latent 32, levels 0/1)"
     if "naf_chain_kernel" in k:
         return "naf_chain (levels 0/1)"
+    if "hca_ending_conv_kernel" in k:
+        return "hca_conv 3x3 + ending conv (one launch)"
     if "hca_conv_kernel" in k:
         return "hca_conv 3x3"
     if "intro_conv" in k or "ending_conv" in k:
