@@ -1140,3 +1140,30 @@ def test_the_cost_of_leaving_the_benchmark_shapes_is_bounded(gpu, weights16):
     assert per_face[65] <= 1.7 * per_face[64], per_face
     assert per_face[128] <= 1.0 * per_face[64], per_face           # measured 0.84x: the per-GEMM launches barely notice the row count
     assert rows[65][2] < 2.0 * rows[64][2] and rows[128][2] < 2.0 * rows[64][2], rows      # passes of 64 would lose at both ends
+
+
+def test_folded_transitions_against_their_launches(gpu, weights16):
+    """r05: the intro conv, downs.0 and ups.3 run as the ENTRY of the face-cluster stage that consumes them and hcas.4 shares a launch with the
+    ending conv (59 launches).  HD_NO_INTRO_FOLD=1 at context creation keeps all four as launches of their own (63): the same eps -- the intro
+    entry and the fused ending are the launches' arithmetic operation for operation (bit-identical on their own), the two GEMM entries differ
+    from their launches by the accumulation order of K and the bf16 roundings that follow -- and the same 24-step DDPM loop to 1e-2."""
+    from hifidiff_amd import _lib, sampling, schedulers, synth
+    L = _lib.lib()
+    m = make_model(weights16)
+    os.environ["HD_NO_INTRO_FOLD"] = "1"
+    try:
+        m0 = make_model(weights16)
+    finally:
+        del os.environ["HD_NO_INTRO_FOLD"]
+    sch = schedulers.DDPMScheduler(clip_sample_range=3.0)
+    sch.timesteps = sch.timesteps[:24]
+    for B in (64, 3):
+        x, crl, crf = [t.cuda() for t in synth.sample_inputs(B, 16)]
+        e1 = m(x, 500, crf, crl).sample.clone()
+        e0 = m0(x, 500, crf, crl).sample.clone()
+        assert (L.hd_num_ops(m.engine.ctx, 0), L.hd_num_ops(m0.engine.ctx, 0)) == (59, 63)
+        assert [L.hd_get_option(m0.engine.ctx, k) for k in (b"intro_fold", b"down_fold", b"up_fold")] == [0, 0, 0]
+        assert bool(torch.isfinite(e1).all()) and rel_l2(e1.cpu(), e0.cpu()) <= 3e-3, (B, rel_l2(e1.cpu(), e0.cpu()))
+        a = sampling.sample(m, x, crf, crl, sch, seed=5)
+        b = sampling.sample(m0, x, crf, crl, sch, seed=5)
+        assert rel_l2(a.cpu(), b.cpu()) <= 1e-2, (B, rel_l2(a.cpu(), b.cpu()))
