@@ -110,6 +110,11 @@ for k, (name, a) in enumerate(zip(ops, avg)):
     else:
         key = name
     w, act = op_bytes(name)
+    if name == "ending" and L == 16 and "hcas.4" not in ops and "hcas.3" in ops:
+        # hd_end.hpp: the last HCA conv and the ending conv in one launch -- the HCA weights and its bf16 input, no fp32 round trip of its output
+        key = "hcas.4 + ending (one launch)"
+        w += 9 * 128 * 128 * 2
+        act = B * L * L * 128 * 2 + B * 4 * L * L * 4 * 3
     g = groups.setdefault(key, [0, 0.0, 0, 0])
     g[0] += 1; g[1] += a; g[2] += w; g[3] += act
 print("one diffusion step, batch %d, latent %d: %d launches, %.1f us of kernel time (%d steps averaged)" % (B, L, n, sum(avg), len(starts)))
