@@ -42,6 +42,9 @@ def test_no_scratch_in_the_hot_kernels(recs):
     assert len(stages) == len(BENCH_STAGES), [_p(r)[:60] for r in stages]
     bad = [(_p(r)[:80], r["scratch"], r["vgpr_spill"], r["scratch_bytes"]) for r in stages if r["scratch"] or r["vgpr_spill"] or r["scratch_bytes"]]
     assert not bad, bad
+    # the step's last launch (hd_end.hpp: the last HCA conv + the ending conv): one copy per translation unit that includes it
+    ends = [r for r in recs if _p(r).startswith("hca_ending_conv_kernel")]
+    assert ends and not [r for r in ends if r["scratch"] or r["vgpr_spill"] or r["scratch_bytes"]], [(_p(r)[:60], r["scratch"]) for r in ends]
     # latent 32, level 0 by strips (hd_strip.hpp); the level-1 form (C = 256) carries 12 spilled registers around an MFMA / VALU overlap
     strips = [r for r in recs if _p(r).startswith("naf_strip_dwgate_kernel<128, 32>")]
     assert len(strips) == 1 and not (strips[0]["scratch"] or strips[0]["vgpr_spill"]), [(_p(r)[:60], r["scratch"]) for r in strips]

@@ -24,7 +24,7 @@ BUILD = os.path.join(ROOT, "hifidiff_amd", "csrc", "build")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 # kernels of the benchmark's 59-launch step that must hold no scratch access
-HOT_PREFIXES = ("xcd_stage_kernel", "xcd2_stage_kernel", "naf_face_stage_kernel", "naf_chain_kernel", "naf_strip_dwgate_kernel")
+HOT_PREFIXES = ("xcd_stage_kernel", "xcd2_stage_kernel", "naf_face_stage_kernel", "naf_chain_kernel", "naf_strip_dwgate_kernel", "hca_ending_conv_kernel")
 BAD_OPSEL = re.compile(r"op_sel:\[0,1,0\]\s+op_sel_hi:\[1,1,0\]")
 
 
